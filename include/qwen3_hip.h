@@ -1,0 +1,151 @@
+/*
+ * qwen3_hip.h -- C ABI of libqwen3_hip.so, the MI355X (gfx950) Qwen3 Q8 decode engine.
+ *
+ * Drop-in boundary: the reference has no FFI; its seam is the Rust trait
+ *     pub trait Transformer { fn forward(&mut self, token: usize, pos: usize) -> &[f32];
+ *                             fn get_config(&self) -> &ModelConfig; }
+ * (qwen3-inference/src/models/mod.rs:13-18), built by TransformerBuilder::build (models/mod.rs:55-73).
+ * A `Transformers::Qwen3Hip` variant inside qwen3-inference binds exactly the entry points of section 1
+ * (INTEGRATION.md shows the ~80-line Rust shim).  Plain pointers and sizes only; no torch / HIP types.
+ *
+ * Threading: one caller at a time per engine (mirrors `&mut self`); engines are independent, one per
+ * GPU, no communication (replicas only -- the path does not shard).
+ * Errors: 0 on success, negative q3_status otherwise; q3_last_error() gives the calling thread's
+ * message.  There is NO CPU fallback: without a usable HIP device q3_create fails.
+ */
+#ifndef QWEN3_HIP_H
+#define QWEN3_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define Q3_ABI_VERSION 1
+
+typedef enum q3_status {
+    Q3_OK = 0,
+    Q3_ERR_IO = -1,        /* open / mmap failed                        (models/mod.rs:56-59) */
+    Q3_ERR_FORMAT = -2,    /* bad magic / version / dims / truncated    (configuration.rs:116-146, utils.rs:21-56) */
+    Q3_ERR_ARG = -3,       /* null pointer, token/pos out of range (the reference panics: layers.rs:73-75,335) */
+    Q3_ERR_HIP = -4,       /* HIP runtime error / no device */
+    Q3_ERR_UNSUPPORTED = -5 /* shape the kernels do not cover (e.g. group_size not a multiple of 16) */
+} q3_status;
+
+/* ModelConfig, qwen3-inference/src/configuration.rs:18-30 (seq_len already clamped by ctx_len) */
+typedef struct q3_config {
+    int32_t architecture_id;
+    int32_t dim;
+    int32_t hidden_dim;
+    int32_t n_layers;
+    int32_t n_heads;
+    int32_t n_kv_heads;
+    int32_t head_dim;
+    int32_t seq_len;
+    int32_t vocab_size;
+    int32_t group_size;
+    int32_t shared_classifier; /* bool */
+} q3_config;
+
+typedef struct q3_engine q3_engine;
+
+/* q3_create flags.
+ * Default (flags = 0): every f32 sum is reduced in the reference's sequential order, so logits are
+ * BIT-IDENTICAL to the CPU path and greedy token sequences are identical by construction. */
+#define Q3_FLAG_FAST 1u /* opt-in: wavefront-tree reductions for the RMSNorm / attention sums.  Not
+                           bit-exact: a 28-layer W8A8 stack amplifies a 1e-7 reordering difference to its
+                           own int8 quantization-noise floor (logit deltas of ~0.1), so
+                           greedy tokens can differ from the CPU path.  The int8 group-quant matmul itself
+                           is bit-exact in both modes. */
+#define Q3_FLAG_NO_GRAPH 2u /* launch kernels eagerly instead of replaying a captured hipGraph */
+
+/* ------------------------------------------------------------------------------------------------
+ * 1. The reference surface
+ * ---------------------------------------------------------------------------------------------- */
+
+/* TransformerBuilder::new(path).with_ctx_length(ctx).build()          models/mod.rs:45-73
+ * ctx_len 0 = keep the checkpoint's seq_len.  device = HIP device ordinal. */
+int q3_create(const char* checkpoint_path, uint32_t ctx_len, int device, uint32_t flags, q3_engine** out);
+
+/* Transformer::get_config                                              models/mod.rs:17 */
+int q3_get_config(const q3_engine* e, q3_config* out);
+
+/* Transformer::forward(token, pos) -> &[f32; vocab_size]               models/qwen3.rs:62-79
+ * Returns a host pointer to vocab_size logits, valid until the next call on this engine (same lifetime
+ * as the reference's borrow from &mut self), or NULL on error (the Rust shim panics, as the reference
+ * does on out-of-range indices). */
+const float* q3_forward(q3_engine* e, size_t token, size_t pos);
+
+/* Drop for the transformer */
+void q3_destroy(q3_engine* e);
+
+const char* q3_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * 2. Extensions outside the reference surface (same arithmetic, less egress)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* forward + Sampler::sample_argmax (sampler.rs:57-59: last maximum under f32::total_cmp) on the device;
+ * only the 4-byte token id crosses PCIe. */
+int q3_forward_argmax(q3_engine* e, size_t token, size_t pos, int32_t* next_token);
+
+/* The greedy inner loop of `generate` (generation.rs:31-46,153-162 with temperature 0) kept on the
+ * device: step k runs forward(tok_k, first_pos + k) and tok_{k+1} = argmax.  tok_0 = first_token.
+ * Writes tok_1..tok_n into out_tokens (n = n_tokens).  No termination check: callers cut at BOS/EOS
+ * (generation.rs:35) afterwards.  Requires first_pos + n_tokens <= seq_len. */
+int q3_generate_greedy(q3_engine* e, size_t first_token, size_t first_pos, size_t n_tokens, int32_t* out_tokens);
+
+/* Fresh-engine state: zero the KV cache (models/qwen3.rs:439-440) */
+int q3_reset_kv(q3_engine* e);
+
+/* Copy device state back for parity tests: kind 0 = key cache, 1 = value cache ([L][seq_len][kv_dim]),
+ * 2 = x after the final RMSNorm ([dim]).  `count` floats starting at `offset`. */
+int q3_read_state(q3_engine* e, int kind, size_t offset, size_t count, float* out);
+
+/* Per-kernel timing of one forward(token,pos), launched eagerly with HIP events around every kernel
+ * on the engine's stream.  Kernel families are listed by q3_profile_names(); ms[i] / launches[i] are
+ * accumulated over `reps` forwards.  Returns the number of families (<= cap). */
+int q3_profile(q3_engine* e, size_t token, size_t pos, int reps, float* ms, int32_t* launches, int cap);
+const char* q3_profile_name(int family);
+
+/* Header parse + validation only (configuration.rs:77-146); does not touch the GPU. */
+int q3_parse_header(const uint8_t* data, size_t len, q3_config* out);
+
+uint32_t q3_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * 3. Operator-level entry points: the reference's public free functions (tensor.rs, layers.rs) run on
+ *    the device over caller (host) buffers.  Used by the parity tests; same kernels/device functions
+ *    as the fused forward.  `device` as in q3_create; flags: 0 (reference order) or Q3_FLAG_FAST.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* tensor::quantize(qx, x, size, group_size)                             tensor.rs:91-119 */
+int q3_op_quantize(int8_t* q, float* s, const float* x, size_t size, size_t group_size, int device);
+/* tensor::dequantize                                                    tensor.rs:72-80 */
+int q3_op_dequantize(const int8_t* q, const float* s, float* x, size_t size, size_t group_size, int device);
+/* tensor::matmul(xout, x, w, n, d, group_size)                          tensor.rs:23-62 */
+int q3_op_matmul(float* xout, const int8_t* xq, const float* xs, const int8_t* wq, const float* ws, size_t n,
+                 size_t d, size_t group_size, int device);
+/* RMSNorm::forward                                                      layers.rs:109-119 */
+int q3_op_rmsnorm(float* out, const float* in, const float* weight, size_t n, uint32_t flags, int device);
+/* layers::softmax                                                       layers.rs:495-506 */
+int q3_op_softmax(float* x, size_t n, uint32_t flags, int device);
+/* FeedForward SwiGLU: hb = hb*sigmoid(hb)*hb2                           layers.rs:472-475 */
+int q3_op_swiglu(float* hb, const float* hb2, size_t n, int device);
+/* f32::exp as the device computes it (glibc expf algorithm), elementwise */
+int q3_op_expf(float* x, size_t n, int device);
+/* MultiHeadAttention: QK-RMSNorm + RoPE + GQA attention of ONE layer    layers.rs:346-419
+ * key/value: the layer's cache [seq_len][kv_dim] (row `pos` holds the raw k/v projections on entry;
+ * on return the K row is normalised+rotated in place).  q: [n_heads*head_dim] in/out.  xb: output. */
+int q3_op_attention(float* xb, float* q, float* key_cache_layer, const float* value_cache_layer,
+                    const float* q_norm_w, const float* k_norm_w, size_t pos, size_t seq_len, size_t n_heads,
+                    size_t n_kv_heads, size_t head_dim, uint32_t flags, int device);
+/* Sampler::sample_argmax                                                sampler.rs:57-59 */
+int q3_op_argmax(const float* logits, size_t n, int32_t* index, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QWEN3_HIP_H */

@@ -1,0 +1,988 @@
+// q3_engine.hip -- host side of libqwen3_hip.so: checkpoint loader, launch plan, hipGraph, C ABI.
+//
+// Mirrors, for the hot path only, what qwen3-inference does around `Transformer::forward`:
+//   TransformerBuilder::build            models/mod.rs:55-73      -> q3_create
+//   read_config / validate_config        configuration.rs:77-146  -> parse_header
+//   MemoryMapper + load_weights          utils.rs, qwen3.rs:199-277 -> Engine::load (mmap -> one HBM blob)
+//   TransformerBlockBuffers::new         qwen3.rs:414-445         -> device scratch + zero-filled f32 KV cache
+//   Qwen3Transformer::forward            qwen3.rs:62-79           -> Engine::enqueue_forward (kernel chain)
+// There is deliberately no CPU fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+
+#include <errno.h>
+#include <fcntl.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/qwen3_hip.h"
+#include "q3_kernels.h"
+
+namespace {
+
+using namespace q3;
+
+thread_local char g_err[1024] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            return fail(Q3_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr int32_t kMagic = 0x616a6331;   // configuration.rs:8
+constexpr int32_t kVersion = 1;          // configuration.rs:10
+constexpr size_t kHeaderSize = 256;      // configuration.rs:12
+constexpr size_t kConfigSize = 52;       // 13 x i32
+
+int32_t rd_i32(const uint8_t* p) {
+    return (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24));
+}
+
+// configuration.rs:77-146
+int parse_header(const uint8_t* d, size_t len, q3_config* c) {
+    if (!d || !c) return fail(Q3_ERR_ARG, "null argument");
+    if (len < kConfigSize)
+        return fail(Q3_ERR_FORMAT, "Insufficient data: need %zu bytes, have %zu remaining", kConfigSize, len);
+    if (len < kHeaderSize)
+        return fail(Q3_ERR_FORMAT, "Cannot skip %zu bytes: insufficient data", kHeaderSize - kConfigSize);
+    const int32_t magic = rd_i32(d), version = rd_i32(d + 4);
+    if (magic != kMagic)
+        return fail(Q3_ERR_FORMAT, "Invalid model configuration: Invalid checkpoint magic number: expected %#x, got %#x",
+                    kMagic, (unsigned)magic);
+    if (version != kVersion)
+        return fail(Q3_ERR_FORMAT, "Invalid model configuration: Unsupported checkpoint version: expected %d, got %d",
+                    kVersion, version);
+    c->architecture_id = rd_i32(d + 8);
+    c->dim = rd_i32(d + 12);
+    c->hidden_dim = rd_i32(d + 16);
+    c->n_layers = rd_i32(d + 20);
+    c->n_heads = rd_i32(d + 24);
+    c->n_kv_heads = rd_i32(d + 28);
+    c->vocab_size = rd_i32(d + 32);
+    c->seq_len = rd_i32(d + 36);
+    c->head_dim = rd_i32(d + 40);
+    c->shared_classifier = rd_i32(d + 44) != 0;
+    c->group_size = rd_i32(d + 48);
+    const char* names[8] = {"architecture_id", "dim", "n_layers", "n_heads", "n_kv_heads", "vocab_size", "seq_len", "head_dim"};
+    const int32_t vals[8] = {c->architecture_id, c->dim, c->n_layers, c->n_heads, c->n_kv_heads, c->vocab_size, c->seq_len, c->head_dim};
+    for (int i = 0; i < 8; ++i)
+        if (vals[i] <= 0)
+            return fail(Q3_ERR_FORMAT, "Invalid model configuration: Invalid %s: must be positive, got %d", names[i], vals[i]);
+    return Q3_OK;
+}
+
+bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// shapes the kernels cover (everything the reference README lists, plus small test shapes)
+int check_supported(const q3_config& c) {
+    const int G = c.group_size;
+    if (G < 16 || G > 1024 || !is_pow2(G))
+        return fail(Q3_ERR_UNSUPPORTED, "group_size %d unsupported: must be a power of two in [16,1024]", G);
+    const int ahd = c.n_heads * c.head_dim;
+    if (c.hidden_dim <= 0) return fail(Q3_ERR_FORMAT, "Invalid hidden_dim %d", c.hidden_dim);
+    if (c.dim % G || ahd % G || c.hidden_dim % G)
+        return fail(Q3_ERR_UNSUPPORTED, "dim/all_heads_dim/hidden_dim must be multiples of group_size %d", G);
+    if (c.head_dim % 8 || c.head_dim > 256 || !is_pow2(c.head_dim))
+        return fail(Q3_ERR_UNSUPPORTED, "head_dim %d unsupported: power of two in [8,256] required", c.head_dim);
+    if (c.n_heads % c.n_kv_heads) return fail(Q3_ERR_UNSUPPORTED, "n_heads must be a multiple of n_kv_heads");
+    if (c.dim > 16384 || c.hidden_dim > 65536 || ahd > 16384)
+        return fail(Q3_ERR_UNSUPPORTED, "dimension too large for the LDS-staged activation");
+    return Q3_OK;
+}
+
+struct QT {  // QuantizedTensor view (tensor.rs:5-8) in device memory
+    const int8_t* q = nullptr;
+    const float* s = nullptr;
+};
+
+enum Family { F_QKV = 0, F_ATTN, F_WO, F_W13, F_W2, F_LMHEAD, F_NEXT, F_COUNT };
+const char* kFamilyNames[F_COUNT] = {"qkv", "attn", "wo", "w13", "w2", "lm_head", "next"};
+
+typedef void (*GemvFn)(const GemvArgs);
+
+struct Launch {
+    Family fam;
+    bool is_attn = false, is_next = false;
+    GemvFn fn = nullptr;
+    GemvArgs ga{};
+    AttnArgs aa{};
+    unsigned grid = 1;
+    size_t smem = 0;
+};
+
+// tile shapes instantiated: group 64 (every listed model) gets the full set, other group sizes a
+// single-row-run fallback (RU = 1, or 2 for SwiGLU).
+template <int PRO, int EPI, int LPG_T, int RU>
+GemvFn pick_ju(int JU) {
+    if (JU == 1) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 1>;
+    if (JU == 2) { if constexpr (RU <= 4) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 2>; }
+    if (JU == 4) { if constexpr (RU <= 2) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 4>; }
+    return nullptr;
+}
+template <int PRO, int EPI>
+GemvFn pick(int G, int RU, int JU) {
+    constexpr bool sw = (EPI == EPI_SWIGLU);
+    if (G == 64) {
+        if (RU == 8) return pick_ju<PRO, EPI, 4, 8>(JU);
+        if (RU == 4) return pick_ju<PRO, EPI, 4, 4>(JU);
+        if (RU == 2) return pick_ju<PRO, EPI, 4, 2>(JU);
+        if constexpr (!sw) { if (RU == 1) return pick_ju<PRO, EPI, 4, 1>(JU); }
+        return nullptr;
+    }
+    if constexpr (sw) { if (RU == 2) return pick_ju<PRO, EPI, 0, 2>(JU); }
+    else { if (RU == 1) return pick_ju<PRO, EPI, 0, 1>(JU); }
+    return nullptr;
+}
+
+int set_max_smem(const void* fn, size_t bytes) {
+    if (bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return Q3_OK;
+}
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+}  // namespace
+
+struct q3_engine {
+    q3_config cfg{};
+    uint32_t flags = 0;
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;
+    // device memory
+    uint8_t* d_blob = nullptr;
+    size_t blob_bytes = 0;
+    const float *rms_att = nullptr, *rms_ffn = nullptr, *rms_final = nullptr, *q_ln = nullptr, *k_ln = nullptr;
+    QT tok, wcls;
+    std::vector<QT> wq, wk, wv, wo, w1, w2, w3;
+    float *d_x = nullptr, *d_q = nullptr, *d_kraw = nullptr, *d_xb = nullptr, *d_hb = nullptr, *d_logits = nullptr;
+    float *d_tap = nullptr, *d_key = nullptr, *d_value = nullptr, *d_rope = nullptr, *d_att = nullptr;
+    State* d_state = nullptr;
+    int32_t* d_out_tokens = nullptr;
+    int out_cap = 0;
+    // pinned host staging
+    float* h_logits = nullptr;
+    State* h_state = nullptr;
+    int32_t* h_tokens = nullptr;
+    // launch plan
+    std::vector<Launch> plan;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+
+    int load(const char* path, uint32_t ctx_len);
+    int build_plan();
+    int capture();
+    int enqueue_forward(bool eager);
+    int set_state(size_t token, size_t pos);
+    void release();
+};
+
+namespace {
+
+void launch_one(const Launch& L, q3_engine* e) {
+    if (L.is_attn) {
+        hipLaunchKernelGGL(k_attn, dim3(L.grid), dim3(kWG), L.smem, e->stream, L.aa);
+    } else if (L.is_next) {
+        hipLaunchKernelGGL(k_next, dim3(1), dim3(64), 0, e->stream, e->d_state, e->d_out_tokens, e->out_cap);
+    } else {
+        hipLaunchKernelGGL(L.fn, dim3(L.grid), dim3(kWG), L.smem, e->stream, L.ga);
+    }
+}
+
+// Tile shape + grid for one GEMV launch.  units = output rows (SwiGLU: hidden units, each 2 weight rows).
+// JU follows the row length (1 KiB chunks per row); RU is the largest row count per wave batch that keeps
+// every wave of the grid busy and minimises max rows per wave; larger kernels grid-stride over batches.
+struct GemvShape { int RU, JU; unsigned grid; };
+GemvShape plan_gemv(int units, int n, int G, bool swiglu, int row_align, int n_cu, int wg_per_cu) {
+    GemvShape g;
+    const int nj = (n + 1023) / 1024;
+    g.JU = nj == 1 ? 1 : (nj == 2 ? 2 : 4);
+    const int ru_max = 8 / g.JU, ru_min = swiglu ? 2 : 1;
+    const int waves = n_cu * wg_per_cu * kWaves;
+    int best_ru = ru_min;
+    long best_cost = -1;
+    for (int ru = ru_max; ru >= ru_min; ru >>= 1) {
+        if (G != 64 && ru != ru_min) continue;
+        const int hu = swiglu ? ru / 2 : ru;
+        if (row_align % hu) continue;
+        const long nb = (units + hu - 1) / hu;
+        const long per_wave = (nb + waves - 1) / waves;
+        const long cost = per_wave * ru * 1000 + (ru_max - ru);   // prefer fewer sequential rows, then bigger tiles
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_ru = ru; }
+    }
+    g.RU = best_ru;
+    const int hu = swiglu ? g.RU / 2 : g.RU;
+    const long nb = (units + hu - 1) / hu;
+    long grid = (nb + kWaves - 1) / kWaves;
+    if (grid > (long)n_cu * wg_per_cu) grid = (long)n_cu * wg_per_cu;
+    if (grid < 1) grid = 1;
+    g.grid = (unsigned)grid;
+    return g;
+}
+
+}  // namespace
+
+void q3_engine::release() {
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    void* dptrs[] = {d_blob, d_x, d_q, d_kraw, d_xb, d_hb, d_logits, d_tap, d_key, d_value, d_rope, d_att, d_state, d_out_tokens};
+    for (void* p : dptrs)
+        if (p) (void)hipFree(p);
+    if (h_logits) (void)hipHostFree(h_logits);
+    if (h_state) (void)hipHostFree(h_state);
+    if (h_tokens) (void)hipHostFree(h_tokens);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+// utils.rs MemoryMapper + qwen3.rs:199-277 load_weights: walk the file with a cursor, upload it once.
+int q3_engine::load(const char* path, uint32_t ctx_len) {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(Q3_ERR_IO, "Failed to open checkpoint: %s: %s", path, strerror(errno));
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size <= 0) {
+        close(fd);
+        return fail(Q3_ERR_IO, "Failed to create memory mapping: %s", path);
+    }
+    const size_t flen = (size_t)st.st_size;
+    void* map = mmap(nullptr, flen, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) return fail(Q3_ERR_IO, "Failed to create memory mapping: %s", path);
+    struct Unmap {
+        void* p;
+        size_t n;
+        ~Unmap() { munmap(p, n); }
+    } unmap{map, flen};
+    const uint8_t* base = (const uint8_t*)map;
+
+    int rc = parse_header(base, flen, &cfg);
+    if (rc) return rc;
+    if (ctx_len != 0 && (int64_t)ctx_len < (int64_t)cfg.seq_len) cfg.seq_len = (int32_t)ctx_len;  // models/mod.rs:65-67
+    if (cfg.architecture_id != 1) return fail(Q3_ERR_FORMAT, "Unknown architecture_id: %d", cfg.architecture_id);
+    if ((rc = check_supported(cfg))) return rc;
+
+    const size_t dim = cfg.dim, L = cfg.n_layers, hd = cfg.head_dim, V = cfg.vocab_size, H = cfg.hidden_dim;
+    const size_t G = cfg.group_size, ahd = (size_t)cfg.n_heads * hd, kvd = (size_t)cfg.n_kv_heads * hd;
+
+    // cursor walk (offsets only), mirroring get_f32_slice / get_bytes bounds errors (utils.rs:21-56)
+    size_t off = kHeaderSize;
+    bool ok = true;
+    auto take = [&](size_t bytes, const char* what) -> size_t {
+        if (!ok) return 0;
+        if (off + bytes > flen) {
+            fail(Q3_ERR_FORMAT, "Failed to read %s: Insufficient data: need %zu bytes, have %zu remaining", what, bytes, flen - off);
+            ok = false;
+            return 0;
+        }
+        const size_t o = off;
+        off += bytes;
+        return o;
+    };
+    struct QOff { size_t q, s; };
+    auto take_q = [&](size_t count, size_t size_each, std::vector<QOff>& out) {   // models/mod.rs:83-110
+        for (size_t i = 0; i < count; ++i) {
+            QOff o;
+            o.q = take(size_each, "quantized tensor data");
+            o.s = take(4 * (size_each / G), "scale factors");
+            out.push_back(o);
+        }
+    };
+    const size_t o_rms_att = take(4 * L * dim, "attention normalization weights");
+    const size_t o_rms_ffn = take(4 * L * dim, "FFN normalization weights");
+    const size_t o_rms_final = take(4 * dim, "final normalization weights");
+    const size_t o_q_ln = take(4 * L * hd, "query layer norm weights");
+    const size_t o_k_ln = take(4 * L * hd, "key layer norm weights");
+    std::vector<QOff> otok, owq, owk, owv, owo, ow1, ow2, ow3, ocls;
+    take_q(1, V * dim, otok);
+    take_q(L, dim * ahd, owq);
+    take_q(L, dim * kvd, owk);
+    take_q(L, dim * kvd, owv);
+    take_q(L, ahd * dim, owo);
+    take_q(L, dim * H, ow1);
+    take_q(L, H * dim, ow2);
+    take_q(L, dim * H, ow3);
+    if (!cfg.shared_classifier) take_q(1, dim * V, ocls);
+    if (!ok) return Q3_ERR_FORMAT;
+
+    // every tensor must start 16-byte aligned for dwordx4 loads (true for all listed models: the header
+    // is 256 B and every section size is a multiple of 16)
+    auto aligned = [](size_t o) { return (o & 15) == 0; };
+    bool all_aligned = aligned(o_rms_att) && aligned(o_rms_ffn) && aligned(o_rms_final) && aligned(o_q_ln) && aligned(o_k_ln);
+    for (auto* v : {&otok, &owq, &owk, &owv, &owo, &ow1, &ow2, &ow3, &ocls})
+        for (auto& o : *v) all_aligned = all_aligned && aligned(o.q) && aligned(o.s);
+    if (!all_aligned) return fail(Q3_ERR_UNSUPPORTED, "checkpoint sections are not 16-byte aligned");
+
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+
+    // the whole file becomes one resident HBM blob, layout unchanged (zero repack)
+    blob_bytes = off;
+    HIP_TRY(hipMalloc((void**)&d_blob, blob_bytes));
+    HIP_TRY(hipMemcpy(d_blob, base, blob_bytes, hipMemcpyHostToDevice));
+    auto fp = [&](size_t o) { return (const float*)(d_blob + o); };
+    auto qt = [&](const QOff& o) {
+        QT t;
+        t.q = (const int8_t*)(d_blob + o.q);
+        t.s = (const float*)(d_blob + o.s);
+        return t;
+    };
+    rms_att = fp(o_rms_att);
+    rms_ffn = fp(o_rms_ffn);
+    rms_final = fp(o_rms_final);
+    q_ln = fp(o_q_ln);
+    k_ln = fp(o_k_ln);
+    tok = qt(otok[0]);
+    for (size_t l = 0; l < L; ++l) {
+        wq.push_back(qt(owq[l]));
+        wk.push_back(qt(owk[l]));
+        wv.push_back(qt(owv[l]));
+        wo.push_back(qt(owo[l]));
+        w1.push_back(qt(ow1[l]));
+        w2.push_back(qt(ow2[l]));
+        w3.push_back(qt(ow3[l]));
+    }
+    wcls = cfg.shared_classifier ? tok : qt(ocls[0]);   // qwen3.rs:252-253
+
+    // run state (qwen3.rs:414-445); KV cache zero-filled: generate mode attends over never-written rows
+    const size_t S = cfg.seq_len;
+    const size_t kv_elems = L * S * kvd;
+    HIP_TRY(hipMalloc((void**)&d_x, 4 * dim));
+    HIP_TRY(hipMalloc((void**)&d_q, 4 * ahd));
+    HIP_TRY(hipMalloc((void**)&d_kraw, 4 * kvd));
+    HIP_TRY(hipMalloc((void**)&d_xb, 4 * ahd));
+    HIP_TRY(hipMalloc((void**)&d_hb, 4 * H));
+    HIP_TRY(hipMalloc((void**)&d_logits, 4 * V));
+    HIP_TRY(hipMalloc((void**)&d_tap, 4 * dim));
+    HIP_TRY(hipMalloc((void**)&d_key, 4 * kv_elems));
+    HIP_TRY(hipMalloc((void**)&d_value, 4 * kv_elems));
+    HIP_TRY(hipMemset(d_key, 0, 4 * kv_elems));
+    HIP_TRY(hipMemset(d_value, 0, 4 * kv_elems));
+    HIP_TRY(hipMemset(d_x, 0, 4 * dim));
+    HIP_TRY(hipMalloc((void**)&d_state, sizeof(State)));
+    HIP_TRY(hipMemset(d_state, 0, sizeof(State)));
+    out_cap = (int)S;
+    HIP_TRY(hipMalloc((void**)&d_out_tokens, 4 * (size_t)out_cap));
+    HIP_TRY(hipMemset(d_out_tokens, 0, 4 * (size_t)out_cap));
+    HIP_TRY(hipHostMalloc((void**)&h_logits, 4 * V, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&h_state, sizeof(State), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&h_tokens, 4 * (size_t)out_cap, hipHostMallocDefault));
+
+    // RoPE table with the host libm, exactly RoPE::compute_freqs (layers.rs:161-171)
+    {
+        const size_t half = hd / 2;
+        std::vector<float> tab(S * hd);
+        std::vector<float> freq(half);
+        for (size_t i = 0; i < half; ++i) freq[i] = powf(1e6f, -((float)i) / (float)half);
+        for (size_t p = 0; p < S; ++p)
+            for (size_t i = 0; i < half; ++i) {
+                const float angle = (float)p * freq[i];
+                tab[p * hd + 2 * i] = cosf(angle);
+                tab[p * hd + 2 * i + 1] = sinf(angle);
+            }
+        HIP_TRY(hipMalloc((void**)&d_rope, 4 * tab.size()));
+        HIP_TRY(hipMemcpy(d_rope, tab.data(), 4 * tab.size(), hipMemcpyHostToDevice));
+    }
+    return Q3_OK;
+}
+
+// The per-token kernel chain, in the order of TransformerBlock::forward (qwen3.rs:131-176)
+int q3_engine::build_plan() {
+    const int dim = cfg.dim, L = cfg.n_layers, hd = cfg.head_dim, V = cfg.vocab_size, H = cfg.hidden_dim;
+    const int G = cfg.group_size, ahd = cfg.n_heads * hd, kvd = cfg.n_kv_heads * hd, S = cfg.seq_len;
+    const int strict = (flags & Q3_FLAG_FAST) ? 0 : 1;
+    const int small_cap = env_int("Q3_WG_PER_CU_SMALL", 1);
+    const int big_cap = env_int("Q3_WG_PER_CU_LMHEAD", 4);
+    const int att_lds_max = env_int("Q3_ATT_LDS_MAX", 8192);
+
+    if (S > att_lds_max) HIP_TRY(hipMalloc((void**)&d_att, 4 * (size_t)cfg.n_heads * S));
+
+    auto base_args = [&](int n) {
+        GemvArgs a{};
+        a.n = n;
+        a.group = G;
+        a.strict = strict;
+        a.debug = env_int("Q3_ABLATE", 0);
+        a.st = d_state;
+        a.seq_len = S;
+        return a;
+    };
+    int rc;
+    for (int l = 0; l < L; ++l) {
+        const size_t kv_off = (size_t)l * S * kvd;
+        {   // xb = RMSNorm_att(x); xq = quantize(xb); q,k,v = W{q,k,v} xq         qwen3.rs:134-136, layers.rs:334-337
+            Launch Ln;
+            Ln.fam = F_QKV;
+            GemvArgs a = base_args(dim);
+            a.seg[0] = Seg{wq[l].q, wq[l].s, d_q, ahd, 0};
+            a.seg[1] = Seg{wk[l].q, wk[l].s, d_kraw, kvd, 0};
+            a.seg[2] = Seg{wv[l].q, wv[l].s, d_value + kv_off, kvd, kvd};
+            a.total_rows = ahd + 2 * kvd;
+            for (int k = 0; k < 2; ++k) {
+                a.qkv_dw[k] = (const char*)a.seg[k + 1].wq - (const char*)a.seg[k].wq;
+                a.qkv_ds[k] = (const char*)a.seg[k + 1].ws - (const char*)a.seg[k].ws;
+                a.qkv_do[k] = (const char*)a.seg[k + 1].out - (const char*)a.seg[k].out;
+            }
+            a.norm_w = rms_att + (size_t)l * dim;
+            a.in = d_x;
+            const GemvShape gs = plan_gemv(a.total_rows, dim, G, false, hd, n_cu, small_cap);
+            if (l == 0) {
+                a.emb_q = tok.q;
+                a.emb_s = tok.s;
+                a.x_out = d_x;
+                Ln.fn = pick<PRO_EMBED_NORM, EPI_QKV>(G, gs.RU, gs.JU);
+            } else {
+                Ln.fn = pick<PRO_NORM, EPI_QKV>(G, gs.RU, gs.JU);
+            }
+            a.vr = gs.RU;
+            Ln.grid = gs.grid;
+            Ln.smem = gemv_smem_bytes(dim, G, a.vr, true);
+            Ln.ga = a;
+            if (!Ln.fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel instantiated for this tile shape");
+            if ((rc = set_max_smem((const void*)Ln.fn, Ln.smem))) return rc;
+            plan.push_back(Ln);
+        }
+        {   // QK-norm + RoPE + attention                                        layers.rs:346-419
+            Launch Ln;
+            Ln.fam = F_ATTN;
+            Ln.is_attn = true;
+            AttnArgs a{};
+            a.q = d_q;
+            a.key_cache = d_key + kv_off;
+            a.k_raw = d_kraw;
+            a.value_cache = d_value + kv_off;
+            a.q_norm_w = q_ln + (size_t)l * hd;
+            a.k_norm_w = k_ln + (size_t)l * hd;
+            a.rope = d_rope;
+            a.xb = d_xb;
+            a.att_global = d_att ? d_att : nullptr;
+            a.st = d_state;
+            a.pos_override = -1;
+            a.n_heads = cfg.n_heads;
+            a.n_kv_heads = cfg.n_kv_heads;
+            a.hd = hd;
+            a.seq_len = S;
+            a.strict = strict;
+            a.write_q = 0;
+            a.debug = env_int("Q3_ABLATE", 0);
+            Ln.aa = a;
+            Ln.grid = (unsigned)cfg.n_heads;
+            Ln.smem = attn_smem_bytes(hd, d_att ? 0 : S);
+            if ((rc = set_max_smem((const void*)k_attn, Ln.smem))) return rc;
+            plan.push_back(Ln);
+        }
+        {   // xq = quantize(xb); x += Wo xq                                      qwen3.rs:152-156
+            Launch Ln;
+            Ln.fam = F_WO;
+            GemvArgs a = base_args(ahd);
+            a.seg[0] = Seg{wo[l].q, wo[l].s, d_x, dim, 0};
+            a.total_rows = dim;
+            a.in = d_xb;
+            const GemvShape gs = plan_gemv(dim, ahd, G, false, 1, n_cu, small_cap);
+            Ln.fn = pick<PRO_QUANT, EPI_RESID>(G, gs.RU, gs.JU);
+            a.vr = gs.RU;
+            Ln.grid = gs.grid;
+            Ln.smem = gemv_smem_bytes(ahd, G, a.vr, false);
+            Ln.ga = a;
+            if (!Ln.fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel instantiated for this tile shape");
+            if ((rc = set_max_smem((const void*)Ln.fn, Ln.smem))) return rc;
+            plan.push_back(Ln);
+        }
+        {   // xb = RMSNorm_ffn(x); xq = quantize(xb); hb = silu(W1 xq) * (W3 xq)   qwen3.rs:159-161, layers.rs:468-475
+            Launch Ln;
+            Ln.fam = F_W13;
+            GemvArgs a = base_args(dim);
+            a.seg[0] = Seg{w1[l].q, w1[l].s, d_hb, H, 0};
+            a.seg[1] = Seg{w3[l].q, w3[l].s, nullptr, H, 0};
+            a.total_rows = 2 * H;
+            a.norm_w = rms_ffn + (size_t)l * dim;
+            a.in = d_x;
+            const GemvShape gs = plan_gemv(H, dim, G, true, 1, n_cu, small_cap);
+            Ln.fn = pick<PRO_NORM, EPI_SWIGLU>(G, gs.RU, gs.JU);
+            a.vr = gs.RU;
+            Ln.grid = gs.grid;
+            Ln.smem = gemv_smem_bytes(dim, G, a.vr, true);
+            Ln.ga = a;
+            if (!Ln.fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel instantiated for this tile shape");
+            if ((rc = set_max_smem((const void*)Ln.fn, Ln.smem))) return rc;
+            plan.push_back(Ln);
+        }
+        {   // hq = quantize(hb); x += W2 hq                                      layers.rs:478-479, qwen3.rs:175
+            Launch Ln;
+            Ln.fam = F_W2;
+            GemvArgs a = base_args(H);
+            a.seg[0] = Seg{w2[l].q, w2[l].s, d_x, dim, 0};
+            a.total_rows = dim;
+            a.in = d_hb;
+            const GemvShape gs = plan_gemv(dim, H, G, false, 1, n_cu, small_cap);
+            Ln.fn = pick<PRO_QUANT, EPI_RESID>(G, gs.RU, gs.JU);
+            a.vr = gs.RU;
+            Ln.grid = gs.grid;
+            Ln.smem = gemv_smem_bytes(H, G, a.vr, false);
+            Ln.ga = a;
+            if (!Ln.fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel instantiated for this tile shape");
+            if ((rc = set_max_smem((const void*)Ln.fn, Ln.smem))) return rc;
+            plan.push_back(Ln);
+        }
+    }
+    {   // x = RMSNorm_final(x); xq = quantize(x); logits = Wcls xq (+ argmax)      qwen3.rs:72-76
+        Launch Ln;
+        Ln.fam = F_LMHEAD;
+        GemvArgs a = base_args(dim);
+        a.seg[0] = Seg{wcls.q, wcls.s, d_logits, V, 0};
+        a.total_rows = V;
+        a.norm_w = rms_final;
+        a.in = d_x;
+        a.tap_out = d_tap;
+        const GemvShape gs = plan_gemv(V, dim, G, false, 1, n_cu, big_cap);
+        Ln.fn = pick<PRO_NORM, EPI_LOGITS>(G, gs.RU, gs.JU);
+        a.vr = gs.RU;
+        Ln.grid = gs.grid;
+        Ln.smem = gemv_smem_bytes(dim, G, a.vr, true);
+        Ln.ga = a;
+        if (!Ln.fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel instantiated for this tile shape");
+        if ((rc = set_max_smem((const void*)Ln.fn, Ln.smem))) return rc;
+        plan.push_back(Ln);
+    }
+    {
+        Launch Ln;
+        Ln.fam = F_NEXT;
+        Ln.is_next = true;
+        plan.push_back(Ln);
+    }
+    return Q3_OK;
+}
+
+int q3_engine::capture() {
+    HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    for (const Launch& L : plan) launch_one(L, this);
+    HIP_TRY(hipStreamEndCapture(stream, &graph));
+    HIP_TRY(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
+    return Q3_OK;
+}
+
+int q3_engine::enqueue_forward(bool eager) {
+    if (graph_exec && !eager) {
+        HIP_TRY(hipGraphLaunch(graph_exec, stream));
+    } else {
+        for (const Launch& L : plan) launch_one(L, this);
+        HIP_TRY(hipGetLastError());
+    }
+    return Q3_OK;
+}
+
+int q3_engine::set_state(size_t token, size_t pos) {
+    if (token >= (size_t)cfg.vocab_size || pos >= (size_t)cfg.seq_len)
+        return fail(Q3_ERR_ARG, "index out of range: token %zu (vocab_size %d), pos %zu (seq_len %d)", token,
+                    cfg.vocab_size, pos, cfg.seq_len);
+    h_state->token = (int)token;
+    h_state->pos = (int)pos;
+    h_state->step = 0;
+    h_state->pad = 0;
+    h_state->argmax = 0ull;
+    HIP_TRY(hipMemcpyAsync(d_state, h_state, sizeof(State), hipMemcpyHostToDevice, stream));
+    return Q3_OK;
+}
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+const char* q3_last_error(void) { return g_err; }
+uint32_t q3_abi_version(void) { return Q3_ABI_VERSION; }
+
+int q3_parse_header(const uint8_t* data, size_t len, q3_config* out) {
+    g_err[0] = 0;
+    return parse_header(data, len, out);
+}
+
+int q3_create(const char* checkpoint_path, uint32_t ctx_len, int device, uint32_t flags, q3_engine** out) {
+    g_err[0] = 0;
+    if (!checkpoint_path || !out) return fail(Q3_ERR_ARG, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(Q3_ERR_HIP, "no HIP device available (libqwen3_hip has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(Q3_ERR_ARG, "device %d out of range (%d devices)", device, ndev);
+    q3_engine* e = new q3_engine();
+    e->flags = flags;
+    e->device = device;
+    int rc = e->load(checkpoint_path, ctx_len);
+    if (rc == Q3_OK) rc = e->build_plan();
+    if (rc == Q3_OK && !(flags & Q3_FLAG_NO_GRAPH)) rc = e->capture();
+    if (rc != Q3_OK) {
+        e->release();
+        delete e;
+        return rc;
+    }
+    *out = e;
+    return Q3_OK;
+}
+
+void q3_destroy(q3_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    e->release();
+    delete e;
+}
+
+int q3_get_config(const q3_engine* e, q3_config* out) {
+    if (!e || !out) return fail(Q3_ERR_ARG, "null argument");
+    *out = e->cfg;
+    return Q3_OK;
+}
+
+const float* q3_forward(q3_engine* e, size_t token, size_t pos) {
+    g_err[0] = 0;
+    if (!e) {
+        fail(Q3_ERR_ARG, "null engine");
+        return nullptr;
+    }
+    if (hipSetDevice(e->device) != hipSuccess) { fail(Q3_ERR_HIP, "hipSetDevice failed"); return nullptr; }
+    if (e->set_state(token, pos) != Q3_OK) return nullptr;
+    if (e->enqueue_forward(false) != Q3_OK) return nullptr;
+    hipError_t err = hipMemcpyAsync(e->h_logits, e->d_logits, 4 * (size_t)e->cfg.vocab_size, hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    if (err != hipSuccess) {
+        fail(Q3_ERR_HIP, "forward failed: %s", hipGetErrorString(err));
+        return nullptr;
+    }
+    return e->h_logits;
+}
+
+int q3_forward_argmax(q3_engine* e, size_t token, size_t pos, int32_t* next_token) {
+    g_err[0] = 0;
+    if (!e || !next_token) return fail(Q3_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = e->set_state(token, pos);
+    if (rc) return rc;
+    if ((rc = e->enqueue_forward(false))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->h_tokens, e->d_out_tokens, 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    *next_token = e->h_tokens[0];
+    return Q3_OK;
+}
+
+int q3_generate_greedy(q3_engine* e, size_t first_token, size_t first_pos, size_t n_tokens, int32_t* out_tokens) {
+    g_err[0] = 0;
+    if (!e || (!out_tokens && n_tokens)) return fail(Q3_ERR_ARG, "null argument");
+    if (n_tokens == 0) return Q3_OK;
+    if (first_pos + n_tokens > (size_t)e->cfg.seq_len)
+        return fail(Q3_ERR_ARG, "first_pos %zu + n_tokens %zu exceeds seq_len %d", first_pos, n_tokens, e->cfg.seq_len);
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = e->set_state(first_token, first_pos);
+    if (rc) return rc;
+    struct timespec t0, t1, t2;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (size_t k = 0; k < n_tokens; ++k)
+        if ((rc = e->enqueue_forward(false))) return rc;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    HIP_TRY(hipMemcpyAsync(e->h_tokens, e->d_out_tokens, 4 * n_tokens, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    clock_gettime(CLOCK_MONOTONIC, &t2);
+    if (getenv("Q3_DEBUG_TIMING"))
+        fprintf(stderr, "[q3] generate_greedy n=%zu enqueue %.1f us, drain %.1f us\n", n_tokens,
+                (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3,
+                (t2.tv_sec - t1.tv_sec) * 1e6 + (t2.tv_nsec - t1.tv_nsec) * 1e-3);
+    memcpy(out_tokens, e->h_tokens, 4 * n_tokens);
+    return Q3_OK;
+}
+
+int q3_reset_kv(q3_engine* e) {
+    if (!e) return fail(Q3_ERR_ARG, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t bytes = 4 * (size_t)e->cfg.n_layers * e->cfg.seq_len * e->cfg.n_kv_heads * e->cfg.head_dim;
+    HIP_TRY(hipMemsetAsync(e->d_key, 0, bytes, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_value, 0, bytes, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return Q3_OK;
+}
+
+int q3_read_state(q3_engine* e, int kind, size_t offset, size_t count, float* out) {
+    if (!e || !out) return fail(Q3_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t kv = (size_t)e->cfg.n_layers * e->cfg.seq_len * e->cfg.n_kv_heads * e->cfg.head_dim;
+    const float* src = nullptr;
+    size_t lim = 0;
+    if (kind == 0) { src = e->d_key; lim = kv; }
+    else if (kind == 1) { src = e->d_value; lim = kv; }
+    else if (kind == 2) { src = e->d_tap; lim = (size_t)e->cfg.dim; }
+    else return fail(Q3_ERR_ARG, "unknown state kind %d", kind);
+    if (offset + count > lim) return fail(Q3_ERR_ARG, "state range out of bounds");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(out, src + offset, 4 * count, hipMemcpyDeviceToHost));
+    return Q3_OK;
+}
+
+const char* q3_profile_name(int family) { return (family >= 0 && family < F_COUNT) ? kFamilyNames[family] : nullptr; }
+
+int q3_profile(q3_engine* e, size_t token, size_t pos, int reps, float* ms, int32_t* launches, int cap) {
+    g_err[0] = 0;
+    if (!e || !ms || !launches || cap < F_COUNT || reps <= 0) return fail(Q3_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(e->device));
+    for (int i = 0; i < cap; ++i) { ms[i] = 0.f; launches[i] = 0; }
+    const size_t nl = e->plan.size();
+    std::vector<hipEvent_t> ev(nl + 1);
+    for (auto& x : ev) HIP_TRY(hipEventCreate(&x));
+    for (int r = 0; r < reps; ++r) {
+        int rc = e->set_state(token, pos);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(ev[0], e->stream));
+        for (size_t i = 0; i < nl; ++i) {
+            launch_one(e->plan[i], e);
+            HIP_TRY(hipEventRecord(ev[i + 1], e->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        for (size_t i = 0; i < nl; ++i) {
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+            ms[e->plan[i].fam] += t;
+            launches[e->plan[i].fam] += 1;
+        }
+    }
+    for (auto& x : ev) (void)hipEventDestroy(x);
+    return F_COUNT;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// operator-level entry points
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        HIP_TRY(hipMalloc(&p, bytes ? bytes : 16));
+        return Q3_OK;
+    }
+    int upload(const void* src, size_t bytes) {
+        int rc = alloc(bytes);
+        if (rc) return rc;
+        if (bytes) HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+        return Q3_OK;
+    }
+    template <class T> T* as() { return (T*)p; }
+};
+int op_begin(int device) {
+    g_err[0] = 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(Q3_ERR_HIP, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(Q3_ERR_ARG, "device %d out of range", device);
+    HIP_TRY(hipSetDevice(device));
+    return Q3_OK;
+}
+int op_end() {
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return Q3_OK;
+}
+bool group_ok(size_t G) { return G >= 16 && G <= 1024 && (G & (G - 1)) == 0; }
+}  // namespace
+
+extern "C" {
+
+int q3_op_quantize(int8_t* q, float* s, const float* x, size_t size, size_t group_size, int device) {
+    int rc = op_begin(device);
+    if (rc) return rc;
+    if (!group_ok(group_size) || size % group_size) return fail(Q3_ERR_UNSUPPORTED, "unsupported size/group_size");
+    DevBuf dx, dq, ds;
+    if ((rc = dx.upload(x, 4 * size)) || (rc = dq.alloc(size)) || (rc = ds.alloc(4 * (size / group_size)))) return rc;
+    hipLaunchKernelGGL(k_op_quantize, dim3(1), dim3(kWG), 0, 0, dq.as<int8_t>(), ds.as<float>(), dx.as<float>(), (int)size, (int)group_size);
+    if ((rc = op_end())) return rc;
+    HIP_TRY(hipMemcpy(q, dq.p, size, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(s, ds.p, 4 * (size / group_size), hipMemcpyDeviceToHost));
+    return Q3_OK;
+}
+
+int q3_op_dequantize(const int8_t* q, const float* s, float* x, size_t size, size_t group_size, int device) {
+    int rc = op_begin(device);
+    if (rc) return rc;
+    if (group_size == 0 || size % group_size) return fail(Q3_ERR_ARG, "size must be a multiple of group_size");
+    DevBuf dx, dq, ds;
+    if ((rc = dq.upload(q, size)) || (rc = ds.upload(s, 4 * (size / group_size))) || (rc = dx.alloc(4 * size))) return rc;
+    hipLaunchKernelGGL(k_op_dequantize, dim3(256), dim3(256), 0, 0, dq.as<int8_t>(), ds.as<float>(), dx.as<float>(), size, (int)group_size);
+    if ((rc = op_end())) return rc;
+    HIP_TRY(hipMemcpy(x, dx.p, 4 * size, hipMemcpyDeviceToHost));
+    return Q3_OK;
+}
+
+int q3_op_matmul(float* xout, const int8_t* xq, const float* xs, const int8_t* wq, const float* ws, size_t n, size_t d,
+                 size_t group_size, int device) {
+    int rc = op_begin(device);
+    if (rc) return rc;
+    if (!group_ok(group_size) || n % group_size || n % 16 || n == 0 || d == 0 || n > 65536)
+        return fail(Q3_ERR_UNSUPPORTED, "unsupported n/group_size");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    DevBuf dxq, dxs, dwq, dws, dout;
+    if ((rc = dxq.upload(xq, n)) || (rc = dxs.upload(xs, 4 * (n / group_size))) || (rc = dwq.upload(wq, n * d)) ||
+        (rc = dws.upload(ws, 4 * (n * d / group_size))) || (rc = dout.alloc(4 * d)))
+        return rc;
+    GemvArgs a{};
+    a.n = (int)n;
+    a.group = (int)group_size;
+    a.seg[0] = Seg{dwq.as<int8_t>(), dws.as<float>(), dout.as<float>(), (int)d, 0};
+    a.total_rows = (int)d;
+    a.pre_q = dxq.as<int8_t>();
+    a.pre_s = dxs.as<float>();
+    const GemvShape gs = plan_gemv((int)d, (int)n, (int)group_size, false, 1, prop.multiProcessorCount, 4);
+    a.vr = gs.RU;
+    const unsigned grid = gs.grid;
+    const size_t smem = gemv_smem_bytes((int)n, (int)group_size, a.vr, false);
+    GemvFn fn = pick<PRO_PREQ, EPI_STORE>((int)group_size, gs.RU, gs.JU);
+    if (!fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel for tile %dx%d", gs.RU, gs.JU);
+    if ((rc = set_max_smem((const void*)fn, smem))) return rc;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kWG), smem, 0, a);
+    if ((rc = op_end())) return rc;
+    HIP_TRY(hipMemcpy(xout, dout.p, 4 * d, hipMemcpyDeviceToHost));
+    return Q3_OK;
+}
+
+int q3_op_rmsnorm(float* out, const float* in, const float* weight, size_t n, uint32_t flags, int device) {
+    int rc = op_begin(device);
+    if (rc) return rc;
+    if (n == 0 || n > 32768) return fail(Q3_ERR_UNSUPPORTED, "unsupported n");
+    DevBuf di, dw, dout;
+    if ((rc = di.upload(in, 4 * n)) || (rc = dw.upload(weight, 4 * n)) || (rc = dout.alloc(4 * n))) return rc;
+    const size_t smem = 4 * (size_t)term_floats((int)n) + 256;
+    if ((rc = set_max_smem((const void*)k_op_rmsnorm, smem))) return rc;
+    hipLaunchKernelGGL(k_op_rmsnorm, dim3(1), dim3(kWG), smem, 0, dout.as<float>(), di.as<float>(), dw.as<float>(), (int)n,
+                       (flags & Q3_FLAG_FAST) ? 0 : 1);
+    if ((rc = op_end())) return rc;
+    HIP_TRY(hipMemcpy(out, dout.p, 4 * n, hipMemcpyDeviceToHost));
+    return Q3_OK;
+}
+
+int q3_op_softmax(float* x, size_t n, uint32_t flags, int device) {
+    int rc = op_begin(device);
+    if (rc) return rc;
+    if (n == 0) return Q3_OK;
+    DevBuf dx;
+    if ((rc = dx.upload(x, 4 * n))) return rc;
+    hipLaunchKernelGGL(k_op_softmax, dim3(1), dim3(kWG), 0, 0, dx.as<float>(), (int)n, (flags & Q3_FLAG_FAST) ? 0 : 1);
+    if ((rc = op_end())) return rc;
+    HIP_TRY(hipMemcpy(x, dx.p, 4 * n, hipMemcpyDeviceToHost));
+    return Q3_OK;
+}
+
+int q3_op_swiglu(float* hb, const float* hb2, size_t n, int device) {
+    int rc = op_begin(device);
+    if (rc) return rc;
+    DevBuf a, b;
+    if ((rc = a.upload(hb, 4 * n)) || (rc = b.upload(hb2, 4 * n))) return rc;
+    hipLaunchKernelGGL(k_op_swiglu, dim3(256), dim3(256), 0, 0, a.as<float>(), b.as<float>(), n);
+    if ((rc = op_end())) return rc;
+    HIP_TRY(hipMemcpy(hb, a.p, 4 * n, hipMemcpyDeviceToHost));
+    return Q3_OK;
+}
+
+int q3_op_expf(float* x, size_t n, int device) {
+    int rc = op_begin(device);
+    if (rc) return rc;
+    DevBuf a;
+    if ((rc = a.upload(x, 4 * n))) return rc;
+    hipLaunchKernelGGL(k_op_expf, dim3(512), dim3(256), 0, 0, a.as<float>(), n);
+    if ((rc = op_end())) return rc;
+    HIP_TRY(hipMemcpy(x, a.p, 4 * n, hipMemcpyDeviceToHost));
+    return Q3_OK;
+}
+
+int q3_op_attention(float* xb, float* q, float* key_cache_layer, const float* value_cache_layer, const float* q_norm_w,
+                    const float* k_norm_w, size_t pos, size_t seq_len, size_t n_heads, size_t n_kv_heads, size_t head_dim,
+                    uint32_t flags, int device) {
+    int rc = op_begin(device);
+    if (rc) return rc;
+    if (pos >= seq_len || n_kv_heads == 0 || n_heads % n_kv_heads || head_dim % 8 || head_dim > 256 ||
+        (head_dim & (head_dim - 1)))
+        return fail(Q3_ERR_UNSUPPORTED, "unsupported attention shape");
+    const size_t ahd = n_heads * head_dim, kvd = n_kv_heads * head_dim;
+    DevBuf dq, dk, dv, dqw, dkw, dxb, drope, dkraw, datt;
+    if ((rc = dq.upload(q, 4 * ahd)) || (rc = dk.upload(key_cache_layer, 4 * seq_len * kvd)) ||
+        (rc = dv.upload(value_cache_layer, 4 * seq_len * kvd)) || (rc = dqw.upload(q_norm_w, 4 * head_dim)) ||
+        (rc = dkw.upload(k_norm_w, 4 * head_dim)) || (rc = dxb.alloc(4 * ahd)) ||
+        (rc = dkraw.upload(key_cache_layer + pos * kvd, 4 * kvd)))
+        return rc;
+    const size_t half = head_dim / 2;
+    std::vector<float> tab(seq_len * head_dim);
+    for (size_t p = 0; p < seq_len; ++p)
+        for (size_t i = 0; i < half; ++i) {
+            const float freq = powf(1e6f, -((float)i) / (float)half);
+            const float angle = (float)p * freq;
+            tab[p * head_dim + 2 * i] = cosf(angle);
+            tab[p * head_dim + 2 * i + 1] = sinf(angle);
+        }
+    if ((rc = drope.upload(tab.data(), 4 * tab.size()))) return rc;
+    const bool att_global = seq_len > 8192;
+    if (att_global && (rc = datt.alloc(4 * n_heads * seq_len))) return rc;
+    AttnArgs a{};
+    a.q = dq.as<float>();
+    a.key_cache = dk.as<float>();
+    a.k_raw = dkraw.as<float>();
+    a.value_cache = dv.as<float>();
+    a.q_norm_w = dqw.as<float>();
+    a.k_norm_w = dkw.as<float>();
+    a.rope = drope.as<float>();
+    a.xb = dxb.as<float>();
+    a.att_global = att_global ? datt.as<float>() : nullptr;
+    a.st = nullptr;
+    a.pos_override = (int)pos;
+    a.n_heads = (int)n_heads;
+    a.n_kv_heads = (int)n_kv_heads;
+    a.hd = (int)head_dim;
+    a.seq_len = (int)seq_len;
+    a.strict = (flags & Q3_FLAG_FAST) ? 0 : 1;
+    a.write_q = 1;
+    const size_t smem = attn_smem_bytes((int)head_dim, att_global ? 0 : (int)seq_len);
+    if ((rc = set_max_smem((const void*)k_attn, smem))) return rc;
+    hipLaunchKernelGGL(k_attn, dim3((unsigned)n_heads), dim3(kWG), smem, 0, a);
+    if ((rc = op_end())) return rc;
+    HIP_TRY(hipMemcpy(xb, dxb.p, 4 * ahd, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(q, dq.p, 4 * ahd, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(key_cache_layer + pos * kvd, (float*)dk.p + pos * kvd, 4 * kvd, hipMemcpyDeviceToHost));
+    return Q3_OK;
+}
+
+int q3_op_argmax(const float* logits, size_t n, int32_t* index, int device) {
+    int rc = op_begin(device);
+    if (rc) return rc;
+    if (!index) return fail(Q3_ERR_ARG, "null argument");
+    if (n == 0) { *index = 0; return Q3_OK; }   // unwrap_or_default
+    DevBuf dl, dc;
+    unsigned long long zero = 0;
+    if ((rc = dl.upload(logits, 4 * n)) || (rc = dc.upload(&zero, 8))) return rc;
+    hipLaunchKernelGGL(k_op_argmax, dim3(256), dim3(kWG), 0, 0, dl.as<float>(), n, dc.as<unsigned long long>());
+    if ((rc = op_end())) return rc;
+    unsigned long long cell = 0;
+    HIP_TRY(hipMemcpy(&cell, dc.p, 8, hipMemcpyDeviceToHost));
+    *index = (int32_t)(cell & 0xffffffffull);
+    return Q3_OK;
+}
+
+}  // extern "C"

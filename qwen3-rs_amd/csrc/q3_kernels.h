@@ -1,0 +1,1071 @@
+// q3_kernels.h -- gfx950 (MI355X) device code for the Qwen3 Q8 decode hot path.
+//
+// One token = one chain of weight-streaming kernels (5 per layer + classifier + bookkeeping), replayed
+// from a hipGraph.  Every matmul is an int8 x int8 group-quantized GEMV (1 MAC per weight byte): the
+// bound is HBM bandwidth, so the kernels are built around 16-byte-per-lane coalesced non-temporal
+// loads of the checkpoint blob (one wavefront-load = 1 KiB of one weight row), v_dot4 integer dots,
+// DPP cross-lane reductions and per-wave LDS scratch -- no MFMA (nothing to reuse at batch 1).
+//
+// Numerics follow the reference (reinterpretcat/qwen3-rs, qwen3-inference/src) operation by operation;
+// the file is compiled with -ffp-contract=off so a*b+c is never fused, like rustc's output:
+//   * matmul (tensor.rs:23-62): the i32 group dot is exact; each group term ((f32)dot*ws)*xs is formed
+//     by one lane and the terms are summed in ascending group order by one lane => bit-identical to the
+//     CPU result in every mode.
+//   * RMSNorm / attention / softmax sums (layers.rs:109-131,374-419,495-506): default mode reduces with
+//     wavefront trees (order differs from the CPU => tolerance); strict mode walks them sequentially in
+//     the reference order => bit-identical logits.
+//   * expf: glibc's algorithm (double-precision exp2 table + cubic), restated; RoPE cos/sin come from a
+//     host-built glibc table.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace q3 {
+
+constexpr int kWG = 256;       // threads per workgroup
+constexpr int kWaves = 4;      // wavefronts (64 lanes) per workgroup
+constexpr int kMaxVR = 8;      // weight rows a wave finishes per batch
+constexpr float kEps = 1e-6f;  // layers.rs:6
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// cross-lane helpers.  DPP controls: quad_perm(1,0,3,2)=0xB1, quad_perm(2,3,0,1)=0x4E,
+// row_half_mirror=0x141, row_mirror=0x140.  After each step every lane of the (growing) aligned
+// group holds the group's reduction, so the sequence is an all-reduce for commutative exact ops.
+// ------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(dpp_i<CTRL>(__float_as_int(v)));
+}
+
+// sum over aligned groups of `lanes` consecutive lanes (power of two, wave-uniform)
+__device__ __forceinline__ int group_sum_i32(int v, int lanes) {
+    if (lanes >= 2) v += dpp_i<0xB1>(v);
+    if (lanes >= 4) v += dpp_i<0x4E>(v);
+    if (lanes >= 8) v += dpp_i<0x141>(v);
+    if (lanes >= 16) v += dpp_i<0x140>(v);
+    if (lanes >= 32) v += __shfl_xor(v, 16);
+    if (lanes >= 64) v += __shfl_xor(v, 32);
+    return v;
+}
+template <int LANES>
+__device__ __forceinline__ int group_sum_i32_t(int v) {
+    if (LANES >= 2) v += dpp_i<0xB1>(v);
+    if (LANES >= 4) v += dpp_i<0x4E>(v);
+    if (LANES >= 8) v += dpp_i<0x141>(v);
+    if (LANES >= 16) v += dpp_i<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ float group_max_f32(float v, int lanes) {
+    if (lanes >= 2) v = fmaxf(v, dpp_f<0xB1>(v));
+    if (lanes >= 4) v = fmaxf(v, dpp_f<0x4E>(v));
+    if (lanes >= 8) v = fmaxf(v, dpp_f<0x141>(v));
+    if (lanes >= 16) v = fmaxf(v, dpp_f<0x140>(v));
+    if (lanes >= 32) v = fmaxf(v, __shfl_xor(v, 16));
+    if (lanes >= 64) v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+// tree sum (default mode only: the order differs from the CPU's sequential fold)
+__device__ __forceinline__ float group_sum_f32(float v, int lanes) {
+    if (lanes >= 2) v += dpp_f<0xB1>(v);
+    if (lanes >= 4) v += dpp_f<0x4E>(v);
+    if (lanes >= 8) v += dpp_f<0x141>(v);
+    if (lanes >= 16) v += dpp_f<0x140>(v);
+    if (lanes >= 32) v += __shfl_xor(v, 16);
+    if (lanes >= 64) v += __shfl_xor(v, 32);
+    return v;
+}
+
+// wave-local LDS hand-off: DS operations of one wave execute in issue order, so a compiler-level
+// ordering point is all that is needed between a lane's ds_write and another lane's ds_read.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------------------
+// f32::exp == glibc expf (sysdeps/ieee754/flt-32/e_expf.c, the exp2f_data table with N = 32):
+// exp(x) = 2^(k/N) * 2^(r/N), k = round(x*N/ln2) by the 1.5*2^52 shift, cubic in r, all in double.
+// ------------------------------------------------------------------------------------------------
+__device__ __constant__ unsigned long long kExp2Tab[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+
+__device__ __forceinline__ float q3_expf(float x) {
+    const unsigned ux = __float_as_uint(x);
+    const unsigned abstop = (ux >> 20) & 0x7ffu;
+    if (abstop >= 0x42bu) {  // |x| >= 88.0f
+        if (ux == 0xff800000u) return 0.0f;
+        if (abstop >= 0x7f8u) return x + x;
+        if (x > 0x1.62e42ep6f) return __builtin_inff();
+        if (x < -0x1.9fe368p6f) return 0.0f;
+    }
+    constexpr double kInvLn2N = 0x1.71547652b82fep+0 * 32.0;
+    constexpr double kShift = 0x1.8p+52;
+    constexpr double kC0 = 0x1.c6af84b912394p-5 / 32.0 / 32.0 / 32.0;
+    constexpr double kC1 = 0x1.ebfce50fac4f3p-3 / 32.0 / 32.0;
+    constexpr double kC2 = 0x1.62e42ff0c52d6p-1 / 32.0;
+    const double xd = (double)x;
+    double z = kInvLn2N * xd;
+    double kd = z + kShift;
+    const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+    kd -= kShift;
+    const double r = z - kd;
+    const unsigned long long t = kExp2Tab[ki & 31u] + (ki << 47);
+    const double s = __longlong_as_double((long long)t);
+    z = kC0 * r + kC1;
+    const double r2 = r * r;
+    double y = kC2 * r + 1.0;
+    y = z * r2 + y;
+    y = y * s;
+    return (float)y;
+}
+
+// f32::total_cmp key (sampler.rs:57-59): unsigned order of the key == IEEE total order
+__device__ __forceinline__ unsigned total_order_key(float f) {
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// Rust `(v).round() as i8`: half away from zero, saturating, NaN -> 0
+__device__ __forceinline__ int quant_round_i8(float v) {
+    float r = roundf(v);
+    r = fminf(fmaxf(r, -128.0f), 127.0f);
+    return (r != r) ? 0 : (int)r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device-side run state, advanced by k_next (so a greedy decode loop never returns to the host)
+// ------------------------------------------------------------------------------------------------
+struct State {
+    int token;                      // input token of the current forward
+    int pos;                        // position of the current forward
+    int step;                       // forwards completed since the host last set the state
+    int pad;
+    unsigned long long argmax;      // (total_order_key(logit) << 32) | index, max-reduced
+};
+
+// ------------------------------------------------------------------------------------------------
+// GEMV arguments
+// ------------------------------------------------------------------------------------------------
+enum Pro : int { PRO_PREQ = 0, PRO_QUANT = 1, PRO_NORM = 2, PRO_EMBED_NORM = 3 };
+enum Epi : int { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_LOGITS = 3, EPI_QKV = 4 };
+
+struct Seg {
+    const int8_t* wq;   // [rows][n] int8
+    const float* ws;    // [rows][n/G]
+    float* out;         // destination vector (indexed by row within the segment)
+    int rows;
+    int out_pos_stride; // EPI_QKV: out += pos * out_pos_stride (KV cache row); else 0
+};
+
+struct GemvArgs {
+    Seg seg[3];
+    long long qkv_dw[2], qkv_ds[2], qkv_do[2];  // EPI_QKV: byte deltas seg1-seg0, seg2-seg1 (wq, ws, out)
+    int n;               // contraction length (bytes per weight row)
+    int group;           // quantization group size G
+    int vr;              // rows per wave batch == the kernel's RU template parameter (host bookkeeping)
+    int total_rows;      // sum of seg rows (EPI_SWIGLU: hidden units * 2 handled via seg[0],seg[1])
+    int strict;
+    int debug;           // developer ablation bits (Q3_ABLATE): 1 skip prologue math, 2 skip tiles, 4 skip ordered sum
+    // prologue inputs
+    const float* in;       // PRO_QUANT: f32[n]; PRO_NORM: x f32[n]
+    const float* norm_w;   // PRO_NORM*: RMSNorm weight f32[n]
+    const int8_t* pre_q;   // PRO_PREQ: already-quantized activation
+    const float* pre_s;
+    const int8_t* emb_q;   // PRO_EMBED_NORM: embedding table
+    const float* emb_s;
+    float* x_out;          // PRO_EMBED_NORM: residual stream x (written by workgroup 0)
+    float* tap_out;        // PRO_NORM: optional copy of the normalised vector (workgroup 0)
+    State* st;             // token / pos / argmax cell
+    int seq_len;
+};
+
+// LDS layout of the GEMV kernels (dynamic shared memory, 16-byte aligned carve):
+//   [0, n)                    xq   int8   quantized activation
+//   [n16, +4*n/G)             xs   f32    activation group scales
+//   [.., +4*n)                xf   f32    staged activation (PRO_NORM only)
+//   [.., +4*kWaves*vr*NG)     term f32    per-wave group terms
+//   [.., +64*4)               red  f32    block reduction scratch
+constexpr int kSpecBlocks = 16;   // one DPP row
+constexpr int kSpecPad = 4;       // floats of padding per block: lane j's b128 reads hit distinct banks
+__host__ __device__ inline bool spec_ok(int n) { return n >= 512 && (n % (kSpecBlocks * 32)) == 0; }
+__host__ __device__ inline int term_floats(int n) { return n + kSpecBlocks * kSpecPad; }
+
+struct GemvSmem {
+    int8_t* xq;
+    float* xs;
+    float* xf;
+    float* term;
+    float* red;
+};
+__host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~size_t(15); }
+__host__ __device__ inline size_t gemv_smem_bytes(int n, int group, int vr, bool stage_f32) {
+    size_t b = align16((size_t)n) + align16(4 * (size_t)(n / group));
+    if (stage_f32) b += align16(4 * (size_t)term_floats(n));
+    b += align16(4 * (size_t)kWaves * vr * (n / group));
+    b += 64 * 4;
+    return b;
+}
+__device__ __forceinline__ GemvSmem gemv_carve(char* base, int n, int group, int vr, bool stage_f32) {
+    GemvSmem s;
+    s.xq = (int8_t*)base;
+    base += align16((size_t)n);
+    s.xs = (float*)base;
+    base += align16(4 * (size_t)(n / group));
+    s.xf = (float*)base;
+    if (stage_f32) base += align16(4 * (size_t)term_floats(n));
+    s.term = (float*)base;
+    base += align16(4 * (size_t)kWaves * vr * (n / group));
+    s.red = (float*)base;
+    return s;
+}
+
+// block-wide sum of one float per thread (default mode).  Deterministic order: lane tree, then waves.
+__device__ __forceinline__ float block_sum_fast(float v, float* red) {
+    v = group_sum_f32(v, 64);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    float t = red[0];
+    for (int w = 1; w < kWaves; ++w) t += red[w];
+    __syncthreads();
+    return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = group_max_f32(v, 64);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    float t = red[0];
+    for (int w = 1; w < kWaves; ++w) t = fmaxf(t, red[w]);
+    __syncthreads();
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exact sequential f32 sums (Rust `iter.sum::<f32>()`, strict left fold) without a 1024-deep dependent
+// chain.  `t` holds the terms; the result is bit-identical to  (((-0.0 + t0) + t1) + ...).
+//
+// seq_chain():  one lane-uniform left fold over a contiguous run, LDS reads software-pipelined.
+// seq_sum_spec():  16 lanes fold 16 blocks concurrently from GUESSED running sums.  Adding a block of
+//   small non-negative terms to a large accumulator is (barring ties / binade crossings) a translation,
+//   out(s + d) = out(s) + d, so one correction sweep turns approximate guesses into (almost always)
+//   exact block inputs; a second fold VERIFIES them bitwise (out_j == in_{j+1} for all j).  If any link
+//   fails the loop repeats: block 0's input is exact by construction and round r fixes block r, so it
+//   terminates, exact, in <= 16 rounds (2 in practice).  ~4x shorter critical path than the plain chain.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float chain4(float s, v4f v) {
+    s = s + v.x; s = s + v.y; s = s + v.z; s = s + v.w;
+    return s;
+}
+// nq = number of float4 in the run (>= 1); p 16-byte aligned
+__device__ __forceinline__ float seq_chain(float s, const v4f* p, int nq) {
+    int q = 0;
+    for (; q + 8 <= nq; q += 8) {
+        const v4f a0 = p[q], a1 = p[q + 1], a2 = p[q + 2], a3 = p[q + 3];
+        const v4f a4 = p[q + 4], a5 = p[q + 5], a6 = p[q + 6], a7 = p[q + 7];
+        s = chain4(s, a0); s = chain4(s, a1); s = chain4(s, a2); s = chain4(s, a3);
+        s = chain4(s, a4); s = chain4(s, a5); s = chain4(s, a6); s = chain4(s, a7);
+    }
+    for (; q < nq; ++q) s = chain4(s, p[q]);
+    return s;
+}
+
+// LDS float index of term i in the (possibly padded) term array
+__device__ __forceinline__ int term_index(int i, int n) {
+    if (!spec_ok(n)) return i;
+    const int blen = n / kSpecBlocks;
+    return (i / blen) * (blen + kSpecPad) + (i % blen);
+}
+
+// every lane returns the exact sequential sum of the n terms stored (term_index layout) at t
+__device__ __forceinline__ float seq_sum_terms(const float* t, int n) {
+    if (!spec_ok(n)) {
+        if ((n & 3) == 0) return seq_chain(-0.0f, (const v4f*)t, n >> 2);
+        float s = -0.0f;
+        for (int i = 0; i < n; ++i) s = s + t[i];
+        return s;
+    }
+    const int blen = n / kSpecBlocks, nq = blen >> 2;
+    const int j = threadIdx.x & (kSpecBlocks - 1);      // the 4 DPP rows of a wave work redundantly
+    const v4f* blk = (const v4f*)(t + j * (blen + kSpecPad));
+    // approximate block totals (4 independent partial sums: order is irrelevant for a guess)
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+    for (int q = 0; q < nq; ++q) {
+        const v4f v = blk[q];
+        p0 += v.x; p1 += v.y; p2 += v.z; p3 += v.w;
+    }
+    const float tot = (p0 + p1) + (p2 + p3);
+    // guesses g_j = running sum before block j (serial over the 16 lanes of the row, DPP row_shr:1)
+    float g = -0.0f;
+#pragma unroll
+    for (int k = 1; k < kSpecBlocks; ++k) {
+        const float pg = dpp_f<0x111>(g), pt = dpp_f<0x111>(tot);
+        if (j == k) g = pg + pt;
+    }
+    float out = seq_chain(g, blk, nq);
+    for (int round = 0; round < kSpecBlocks + 1; ++round) {
+        // corrected inputs under the translation assumption: s_j = out_{j-1} + (s_{j-1} - g_{j-1})
+        float sc = -0.0f;
+#pragma unroll
+        for (int k = 1; k < kSpecBlocks; ++k) {
+            const float ps = dpp_f<0x111>(sc), po = dpp_f<0x111>(out), pg = dpp_f<0x111>(g);
+            if (j == k) sc = po + (ps - pg);
+        }
+        const float out2 = seq_chain(sc, blk, nq);
+        // verify every link bitwise: input of block j must equal the output of block j-1
+        const float prev = dpp_f<0x111>(out2);
+        const bool ok = (j == 0) || (__float_as_uint(prev) == __float_as_uint(sc));
+        g = sc;
+        out = out2;
+        if (__all(ok)) break;
+    }
+    return __shfl(out, kSpecBlocks - 1);   // block 15's output of lane 15 (row 0)
+}
+
+// quantize 4 consecutive values held by this thread; its quantization group spans `glanes` = G/4
+// consecutive threads (tensor.rs:91-119).  Writes the packed int8 dword and (group leader) the scale.
+__device__ __forceinline__ void quantize4_to_lds(v4f y, int v_idx, int glanes, bool valid, int8_t* xq, float* xs) {
+    float m = fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)));
+    if (!valid) m = 0.0f;
+    m = group_max_f32(m, glanes);
+    const float scale = m / 127.0f;
+    if (valid) {
+        int q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+        if (scale != 0.0f) {
+            q0 = quant_round_i8(y.x / scale);
+            q1 = quant_round_i8(y.y / scale);
+            q2 = quant_round_i8(y.z / scale);
+            q3 = quant_round_i8(y.w / scale);
+        }
+        ((int*)xq)[v_idx] = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((q3 & 0xff) << 24);
+        if ((v_idx % glanes) == 0) xs[v_idx / glanes] = scale;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Prologues: build the quantized activation (xq, xs) in LDS.  Every workgroup does this redundantly
+// (n <= 12288 floats from L2) so that no extra kernel boundary sits between the producer of the
+// activation and the weight stream that consumes it.
+// ------------------------------------------------------------------------------------------------
+// The activation (and RMSNorm weight) loads are ISSUED before the first weight tile and CONSUMED after it
+// is in flight: vmcnt retires in order, so the prologue can run at vmcnt(#tile loads) under the weight
+// stream.  Up to kProSlots float4 slots per thread are prefetched (n <= 4096); longer vectors load the
+// rest inside the loop.
+constexpr int kProSlots = 4;
+struct ProRegs {
+    v4f x[kProSlots];
+    v4f w[kProSlots];
+};
+
+template <int PRO>
+__device__ __forceinline__ void gemv_prologue_issue(const GemvArgs& a, ProRegs& pr) {
+    if (PRO == PRO_PREQ) return;
+    const int nv = a.n >> 2;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < kProSlots; ++k) {
+        const int v = min(tid + k * kWG, nv - 1);
+        if (PRO == PRO_QUANT || PRO == PRO_NORM) pr.x[k] = ((const v4f*)a.in)[v];
+        if (PRO == PRO_NORM || PRO == PRO_EMBED_NORM) pr.w[k] = ((const v4f*)a.norm_w)[v];
+    }
+    if (PRO == PRO_EMBED_NORM) {
+        // TokenEmbedding::forward over the dequantised table (layers.rs:72-76, tensor.rs:72-80)
+        const size_t row = (size_t)a.st->token * (size_t)a.n;
+#pragma unroll
+        for (int k = 0; k < kProSlots; ++k) {
+            const int v = min(tid + k * kWG, nv - 1);
+            const size_t e = row + 4 * (size_t)v;
+            const int packed = *(const int*)(a.emb_q + e);
+            const float sc = a.emb_s[e / (size_t)a.group];
+            pr.x[k].x = (float)(int8_t)(packed & 0xff) * sc;
+            pr.x[k].y = (float)(int8_t)((packed >> 8) & 0xff) * sc;
+            pr.x[k].z = (float)(int8_t)((packed >> 16) & 0xff) * sc;
+            pr.x[k].w = (float)(int8_t)((packed >> 24) & 0xff) * sc;
+        }
+    }
+}
+
+template <int PRO>
+__device__ __forceinline__ v4f pro_load_x_global(const GemvArgs& a, int v) {
+    if (PRO == PRO_EMBED_NORM) {
+        const size_t e = (size_t)a.st->token * (size_t)a.n + 4 * (size_t)v;
+        const int packed = *(const int*)(a.emb_q + e);
+        const float sc = a.emb_s[e / (size_t)a.group];
+        v4f xv;
+        xv.x = (float)(int8_t)(packed & 0xff) * sc;
+        xv.y = (float)(int8_t)((packed >> 8) & 0xff) * sc;
+        xv.z = (float)(int8_t)((packed >> 16) & 0xff) * sc;
+        xv.w = (float)(int8_t)((packed >> 24) & 0xff) * sc;
+        return xv;
+    }
+    return ((const v4f*)a.in)[v];
+}
+
+__device__ __forceinline__ float sumsq4(v4f xv) {
+    float s0 = xv.x * xv.x;
+    float t = xv.y * xv.y; s0 = s0 + t;
+    t = xv.z * xv.z; s0 = s0 + t;
+    t = xv.w * xv.w; s0 = s0 + t;
+    return s0;
+}
+__device__ __forceinline__ v4f norm4(v4f w, float f, v4f xv) {
+    v4f y;
+    y.x = w.x * (f * xv.x);      // layers.rs:117  w * (factor * x)
+    y.y = w.y * (f * xv.y);
+    y.z = w.z * (f * xv.z);
+    y.w = w.w * (f * xv.w);
+    return y;
+}
+
+template <int PRO>
+__device__ __forceinline__ void gemv_prologue_finish(const GemvArgs& a, const GemvSmem& sm, const ProRegs& pr) {
+    const int n = a.n, G = a.group;
+    const int nv = n >> 2;          // float4 slots
+    const int glanes = G >> 2;      // threads per quantization group
+    const int tid = threadIdx.x;
+    const int nk = (nv + kWG - 1) / kWG;
+    if (PRO == PRO_PREQ) {
+        for (int i = tid; i < (n >> 4); i += kWG) ((v4i*)sm.xq)[i] = ((const v4i*)a.pre_q)[i];
+        for (int i = tid; i < n / G; i += kWG) sm.xs[i] = a.pre_s[i];
+        __syncthreads();
+        return;
+    }
+    if (PRO == PRO_QUANT) {
+#pragma unroll
+        for (int k = 0; k < kProSlots; ++k) {      // static indices: pr stays in registers
+            if (k < nk) {
+                const int v = k * kWG + tid;
+                quantize4_to_lds(pr.x[k], v, glanes, v < nv, sm.xq, sm.xs);
+            }
+        }
+        for (int k = kProSlots; k < nk; ++k) {
+            const int v = k * kWG + tid;
+            const v4f y = ((const v4f*)a.in)[min(v, nv - 1)];
+            quantize4_to_lds(y, v, glanes, v < nv, sm.xq, sm.xs);
+        }
+        __syncthreads();
+        return;
+    }
+    // PRO_NORM / PRO_EMBED_NORM: x -> RMSNorm (layers.rs:109-119) -> quantize (tensor.rs:91-119)
+    float part = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kProSlots; ++k) {
+        const int v = k * kWG + tid;
+        if (k < nk && v < nv) {
+            const v4f xv = pr.x[k];
+            if (PRO == PRO_EMBED_NORM && blockIdx.x == 0) ((v4f*)a.x_out)[v] = xv;
+            v4f sq;
+            sq.x = xv.x * xv.x; sq.y = xv.y * xv.y; sq.z = xv.z * xv.z; sq.w = xv.w * xv.w;
+            *(v4f*)(sm.xf + term_index(4 * v, n)) = sq;      // squares, layers.rs:113
+            part = part + sumsq4(xv);
+        }
+    }
+    for (int k = kProSlots; k < nk; ++k) {
+        const int v = k * kWG + tid;
+        if (v < nv) {
+            const v4f xv = pro_load_x_global<PRO>(a, v);
+            if (PRO == PRO_EMBED_NORM && blockIdx.x == 0) ((v4f*)a.x_out)[v] = xv;
+            v4f sq;
+            sq.x = xv.x * xv.x; sq.y = xv.y * xv.y; sq.z = xv.z * xv.z; sq.w = xv.w * xv.w;
+            *(v4f*)(sm.xf + term_index(4 * v, n)) = sq;
+            part = part + sumsq4(xv);
+        }
+    }
+    float ss;
+    if (a.strict) {
+        __syncthreads();
+        ss = seq_sum_terms(sm.xf, n);
+    } else {
+        ss = block_sum_fast(part, sm.red);
+    }
+    const float f = 1.0f / sqrtf(ss / (float)n + kEps);
+#pragma unroll
+    for (int k = 0; k < kProSlots; ++k) {
+        if (k < nk) {
+            const int v = k * kWG + tid;
+            const bool valid = v < nv;
+            v4f y = {0.f, 0.f, 0.f, 0.f};
+            if (valid) {
+                y = norm4(pr.w[k], f, pr.x[k]);
+                if (a.tap_out != nullptr && blockIdx.x == 0) ((v4f*)a.tap_out)[v] = y;
+            }
+            quantize4_to_lds(y, v, glanes, valid, sm.xq, sm.xs);
+        }
+    }
+    for (int k = kProSlots; k < nk; ++k) {
+        const int v = k * kWG + tid;
+        const bool valid = v < nv;
+        v4f y = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+            y = norm4(((const v4f*)a.norm_w)[v], f, pro_load_x_global<PRO>(a, v));
+            if (a.tap_out != nullptr && blockIdx.x == 0) ((v4f*)a.tap_out)[v] = y;
+        }
+        quantize4_to_lds(y, v, glanes, valid, sm.xq, sm.xs);
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMV body.  A "unit" is one wavefront-load: 64 lanes x 16 B = 1 KiB of one weight row (chunk j of the
+// row).  Lane l owns bytes [16(l+64j), +16): LPG = G/16 adjacent lanes share a quantization group.
+// A tile = RU rows x JU chunks (RU*JU <= 8 units) is loaded into registers in one go; tiles are
+// double-buffered so the next tile's HBM loads are in flight while the current one is reduced, and the
+// very first tile is requested BEFORE the activation prologue (weights depend only on kernel arguments).
+// ------------------------------------------------------------------------------------------------
+template <int LPG_T>
+__device__ __forceinline__ int lpg_sum(int v, int lpg) {
+    if (LPG_T > 0) return group_sum_i32_t<LPG_T>(v);
+    return group_sum_i32(v, lpg);
+}
+
+template <int RU, int JU>
+struct Tile {
+    v4i w[RU][JU];
+    float sc[RU][JU];
+};
+
+// weight rows of one wave batch: `parts` runs (2 for SwiGLU's w1|w3 pair, else 1) of `hu` consecutive
+// rows, the first `cnt` of each run live.  base + row*stride addressing, no pointer arrays.
+struct RowSrc {
+    const int8_t* w[2];
+    const float* s[2];
+    float* out;          // destination vector of the batch's segment, already offset to the batch's row 0
+    int hu;
+    int cnt;
+    int row0;            // row index (within segment) of the batch's first row
+    float resid;         // EPI_RESID: x[row] of this lane's row, requested together with the batch's first tile
+};
+
+// ascending-group sum of one row's terms (Iterator::sum from -0.0 == start at term 0)
+__device__ __forceinline__ float ordered_row_sum(const float* t, int ng) {
+    if ((ng & 3) == 0) {
+        const v4f* tv = (const v4f*)t;
+        v4f v = tv[0];
+        float acc = v.x;
+        acc = acc + v.y; acc = acc + v.z; acc = acc + v.w;
+        const int nq = ng >> 2;
+#pragma unroll 4
+        for (int q = 1; q < nq; ++q) {
+            v = tv[q];
+            acc = acc + v.x; acc = acc + v.y; acc = acc + v.z; acc = acc + v.w;
+        }
+        return acc;
+    }
+    float acc = t[0];
+    for (int g = 1; g < ng; ++g) acc = acc + t[g];
+    return acc;
+}
+
+template <int PRO, int EPI, int LPG_T, int RU, int JU>
+__global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr bool kStage = (PRO == PRO_NORM || PRO == PRO_EMBED_NORM);
+    constexpr int HU = (EPI == EPI_SWIGLU) ? (RU / 2) : RU;   // rows per run
+    static_assert(EPI != EPI_SWIGLU || RU >= 2, "SwiGLU tiles hold a w1 and a w3 row");
+    const GemvSmem sm = gemv_carve(smem_raw, a.n, a.group, RU, kStage);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n = a.n, G = a.group;
+    const int lpg_shift = __builtin_ctz(G >> 4);   // G is a power of two >= 16
+    const int lpg = 1 << lpg_shift;
+    const int ng = n / G;
+    const int nchunks = n >> 4;
+    const int nj = (n + 1023) >> 10;
+    const int njt = (nj + JU - 1) / JU;            // tiles per row batch
+    float* term = sm.term + wave * RU * ng;
+    const int gw = blockIdx.x * kWaves + wave;
+    const int nwaves = gridDim.x * kWaves;
+    const int units = (EPI == EPI_SWIGLU) ? a.seg[0].rows : a.total_rows;   // rows (or hidden units)
+    //   // rows (or hidden units)
+    const int nb = (units + HU - 1) / HU;
+    const int pos = (EPI == EPI_QKV) ? a.st->pos : 0;
+
+    // QKV: segments 1,2 are addressed as byte deltas from segment 0 and blended with 0/1 arithmetic (a
+    // select between pointers loaded from the kernarg segment gets folded by LLVM into a VECTOR load of
+    // the selected kernarg slot, whose wait would drain the activation loads already in flight).
+    const int r0s = a.seg[0].rows, r1s = a.seg[1].rows, r2s = a.seg[2].rows;
+    auto batch_rows = [&](int b) {
+        RowSrc rs;
+        const int row0 = b * HU;
+        const int8_t* wq = a.seg[0].wq;
+        const float* ws = a.seg[0].ws;
+        float* out = a.seg[0].out;
+        int rows = r0s, base = 0, ops = a.seg[0].out_pos_stride;
+        if (EPI == EPI_QKV) {   // batches never straddle segments (segment rows % RU == 0)
+            const long long s1 = row0 >= r0s ? 1 : 0, s2 = row0 >= r0s + r1s ? 1 : 0;
+            wq = wq + s1 * a.qkv_dw[0] + s2 * a.qkv_dw[1];
+            ws = (const float*)((const char*)ws + s1 * a.qkv_ds[0] + s2 * a.qkv_ds[1]);
+            out = (float*)((char*)out + s1 * a.qkv_do[0] + s2 * a.qkv_do[1]);
+            rows = r0s + (int)s1 * (r1s - r0s) + (int)s2 * (r2s - r1s);
+            ops = ops + (int)s1 * (a.seg[1].out_pos_stride - ops) +
+                  (int)s2 * (a.seg[2].out_pos_stride - a.seg[1].out_pos_stride);
+            base = (int)s1 * r0s + (int)s2 * r1s;
+        }
+        const int l0 = row0 - base;
+        rs.row0 = l0;
+        rs.hu = HU;
+        rs.cnt = min(HU, rows - l0);
+        rs.w[0] = wq + (size_t)l0 * n;
+        rs.s[0] = ws + (size_t)l0 * ng;
+        if (EPI == EPI_SWIGLU) {
+            rs.w[1] = a.seg[1].wq + (size_t)l0 * n;
+            rs.s[1] = a.seg[1].ws + (size_t)l0 * ng;
+        } else {
+            rs.w[1] = rs.w[0];
+            rs.s[1] = rs.s[0];
+        }
+        rs.out = out + l0 + ((EPI == EPI_QKV) ? (size_t)pos * ops : 0);
+        rs.resid = (EPI == EPI_RESID) ? rs.out[min(lane, rs.cnt - 1)] : 0.0f;
+        return rs;
+    };
+    auto load_tile = [&](Tile<RU, JU>& T, const RowSrc& rs, int jt) {
+#pragma unroll
+        for (int r = 0; r < RU; ++r) {
+            const int part = (EPI == EPI_SWIGLU && r >= HU) ? 1 : 0;
+            const int lr = min(r - part * HU, rs.cnt - 1);     // tail rows re-read the last live row
+            const int8_t* wrow = rs.w[part] + (size_t)lr * n;
+            const float* srow = rs.s[part] + (size_t)lr * ng;
+#pragma unroll
+            for (int j = 0; j < JU; ++j) {
+                const int c = min(lane + 64 * (jt * JU + j), nchunks - 1);   // tail chunks clamp
+                T.w[r][j] = __builtin_nontemporal_load((const v4i*)wrow + c);
+                T.sc[r][j] = __builtin_nontemporal_load(srow + (c >> lpg_shift));
+            }
+        }
+    };
+    auto compute_tile = [&](const Tile<RU, JU>& T, const RowSrc& rs, int jt) {
+#pragma unroll
+        for (int j = 0; j < JU; ++j) {
+            const int c = lane + 64 * (jt * JU + j);
+            const bool cok = c < nchunks;
+            const int cc = min(c, nchunks - 1);
+            const v4i xv = ((const v4i*)sm.xq)[cc];
+            const float xsc = sm.xs[cc >> lpg_shift];
+#pragma unroll
+            for (int r = 0; r < RU; ++r) {
+                int d = __builtin_amdgcn_sdot4(T.w[r][j].x, xv.x, 0, false);
+                d = __builtin_amdgcn_sdot4(T.w[r][j].y, xv.y, d, false);
+                d = __builtin_amdgcn_sdot4(T.w[r][j].z, xv.z, d, false);
+                d = __builtin_amdgcn_sdot4(T.w[r][j].w, xv.w, d, false);
+                d = lpg_sum<LPG_T>(d, lpg);
+                const int part = (EPI == EPI_SWIGLU && r >= HU) ? 1 : 0;
+                if (cok && (c & (lpg - 1)) == 0 && (r - part * HU) < rs.cnt) {
+                    float t = (float)d * T.sc[r][j];   // tensor.rs:59  ((dot as f32) * ws) * xs
+                    t = t * xsc;
+                    term[r * ng + (c >> lpg_shift)] = t;
+                }
+            }
+        }
+    };
+    unsigned long long best = 0ull;  // EPI_LOGITS running argmax key
+    auto finish = [&](const RowSrc& rs) {
+        wave_lds_sync();
+        if (lane < rs.cnt) {
+            const float acc = (a.debug & 4) ? term[lane * ng] : ordered_row_sum(term + lane * ng, ng);
+            if (EPI == EPI_STORE || EPI == EPI_QKV) {
+                rs.out[lane] = acc;
+            } else if (EPI == EPI_RESID) {
+                rs.out[lane] = rs.resid + acc;          // ResidualConnection::forward, layers.rs:249-259
+            } else if (EPI == EPI_SWIGLU) {
+                const float u = ordered_row_sum(term + (lane + HU) * ng, ng);
+                const float den = 1.0f + q3_expf(-acc);   // layers.rs:472-475
+                const float sw = acc * (1.0f / den);
+                rs.out[lane] = sw * u;
+            } else if (EPI == EPI_LOGITS) {
+                rs.out[lane] = acc;
+                const unsigned long long key =
+                    ((unsigned long long)total_order_key(acc) << 32) | (unsigned)(rs.row0 + lane);
+                best = key > best ? key : best;
+            }
+        }
+        wave_lds_sync();
+    };
+
+    // ---- flat tile sequence of this wave: (batch b, tile jt), b = gw, gw+nwaves, ...
+    // Loads are never issued under a data-dependent branch next to the compute that waits for them:
+    // every compute_tile() sits on a path with a statically known number of younger loads, so hipcc
+    // emits counted vmcnt(N) waits and the next tile streams in while the current one is reduced.
+    int cb = gw, cjt = 0;
+    const bool any = cb < nb;
+    Tile<RU, JU> TA, TB;
+    RowSrc RA, RB;
+    ProRegs pr;
+    gemv_prologue_issue<PRO>(a, pr);          // activation / norm-weight loads go out first ...
+    __builtin_amdgcn_sched_barrier(0);        // (pin the issue order: vmcnt retires in order)
+    RA = batch_rows(min(cb, nb - 1));         // (idle waves re-read a valid batch; nothing is stored)
+    load_tile(TA, RA, 0);                     // ... then the first weight tile ...
+    __builtin_amdgcn_sched_barrier(0);
+    if (a.debug & 1) {
+        for (int i = threadIdx.x; i < (a.n >> 2); i += kWG) ((int*)sm.xq)[i] = 0x01010101;
+        for (int i = threadIdx.x; i < a.n / a.group; i += kWG) sm.xs[i] = 1.0f;
+        __syncthreads();
+    } else
+    gemv_prologue_finish<PRO>(a, sm, pr);     // ... and norm + quantize run under the weight loads
+    if (any && !(a.debug & 2)) {
+        for (;;) {
+            int nb_ = cb, njt_ = cjt + 1;
+            if (njt_ == njt) { njt_ = 0; nb_ = cb + nwaves; }
+            if (nb_ >= nb) {
+                compute_tile(TA, RA, cjt);
+                if (cjt == njt - 1) finish(RA);
+                break;
+            }
+            if (njt_ == 0) RB = batch_rows(nb_); else RB = RA;
+            load_tile(TB, RB, njt_);
+            compute_tile(TA, RA, cjt);
+            if (cjt == njt - 1) finish(RA);
+            cb = nb_; cjt = njt_;
+
+            nb_ = cb; njt_ = cjt + 1;
+            if (njt_ == njt) { njt_ = 0; nb_ = cb + nwaves; }
+            if (nb_ >= nb) {
+                compute_tile(TB, RB, cjt);
+                if (cjt == njt - 1) finish(RB);
+                break;
+            }
+            if (njt_ == 0) RA = batch_rows(nb_); else RA = RB;
+            load_tile(TA, RA, njt_);
+            compute_tile(TB, RB, cjt);
+            if (cjt == njt - 1) finish(RB);
+            cb = nb_; cjt = njt_;
+        }
+    }
+    if (EPI == EPI_LOGITS) {
+        // Sampler::sample_argmax (sampler.rs:57-59): equal keys -> larger index wins == last maximum
+        for (int m = 1; m < 64; m <<= 1) {
+            const unsigned lo = __shfl_xor((unsigned)best, m);
+            const unsigned hi = __shfl_xor((unsigned)(best >> 32), m);
+            const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+            best = o > best ? o : best;
+        }
+        if (lane == 0 && best != 0ull) atomicMax(&a.st->argmax, best);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention: QK-RMSNorm + RoPE (layers.rs:346-372) and GQA attention over cache rows 0..=pos
+// (layers.rs:374-419).  One workgroup per query head.
+// ------------------------------------------------------------------------------------------------
+struct AttnArgs {
+    float* q;                 // [n_heads*hd] raw projections in; normalised+rotated out (workgroup-local use)
+    float* key_cache;         // layer base [seq_len][kv_dim]; row pos is WRITTEN here (normalised + rotated)
+    const float* k_raw;       // [kv_dim] raw k projection of the current position (separate buffer: the head
+                              // workgroups sharing a kv head all read it while one of them writes the cache row)
+    const float* value_cache; // layer base
+    const float* q_norm_w;    // [hd]
+    const float* k_norm_w;    // [hd]
+    const float* rope;        // [seq_len][hd/2][2] (cos,sin) host-built with glibc powf/cosf/sinf
+    float* xb;                // [n_heads*hd] out
+    float* att_global;        // [n_heads][seq_len] scratch when scores do not fit in LDS (else nullptr)
+    const State* st;
+    int pos_override;         // >= 0: use this pos instead of st->pos (operator-level entry point)
+    int n_heads, n_kv_heads, hd, seq_len;
+    int strict;
+    int write_q;              // also write the normalised q back (operator-level parity)
+    int debug;                // ablation: 8 = return right after the q/k norm+rope
+};
+
+__host__ __device__ inline size_t attn_smem_bytes(int hd, int att_lds_floats) {
+    // q[hd] kcur[hd] opart[kWaves][hd] red[64] att[att_lds_floats]
+    return 4 * ((size_t)hd * (2 + kWaves) + 64 + (size_t)att_lds_floats);
+}
+
+// RMSNorm over hd values followed by RoPE, result in dst (LDS).  src: hd raw values in LDS.
+__device__ __forceinline__ void head_norm_rope(float* dst, const float* src, const float* w, const float* cs,
+                                               int hd, int strict, float* red, float* sq) {
+    const int tid = threadIdx.x;
+    float ss;
+    if (strict) {
+        for (int i = tid; i < hd; i += kWG) sq[i] = src[i] * src[i];
+        __syncthreads();
+        ss = seq_sum_terms(sq, hd);
+    } else {
+        float p = 0.0f;
+        for (int i = tid; i < hd; i += kWG) p = p + src[i] * src[i];
+        ss = block_sum_fast(p, red);
+    }
+    const float f = 1.0f / sqrtf(ss / (float)hd + kEps);
+    const int half = hd >> 1;
+    for (int i = tid; i < half; i += kWG) {
+        const float xv = w[i] * (f * src[i]);
+        const float yv = w[i + half] * (f * src[i + half]);
+        const float c = cs[2 * i], s = cs[2 * i + 1];
+        const float a0 = xv * c, b0 = yv * s;
+        const float a1 = xv * s, b1 = yv * c;
+        dst[i] = a0 - b0;            // layers.rs:181-182
+        dst[i + half] = a1 + b1;
+    }
+}
+
+__global__ __launch_bounds__(kWG) void k_attn(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int hd = a.hd;
+    float* q_s = (float*)smem_raw;
+    float* k_s = q_s + hd;
+    float* opart = k_s + hd;
+    float* red = opart + kWaves * hd;
+    float* att_l = red + 64;
+
+    const int h = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kv_mul = a.n_heads / a.n_kv_heads;
+    const int kvh = h / kv_mul;
+    const int kvd = a.n_kv_heads * hd;
+    const int pos = a.pos_override >= 0 ? a.pos_override : a.st->pos;
+    float* att = a.att_global ? a.att_global + (size_t)h * a.seq_len : att_l;
+    const float* cs = a.rope + (size_t)pos * hd;  // hd/2 (cos,sin) pairs
+
+    // ---- stage raw q head and raw k row (current position) into LDS
+    float* krow = a.key_cache + (size_t)pos * kvd + (size_t)kvh * hd;
+    for (int i = tid; i < hd; i += kWG) {
+        opart[i] = a.q[(size_t)h * hd + i];
+        opart[hd + i] = a.k_raw[(size_t)kvh * hd + i];
+    }
+    __syncthreads();
+    head_norm_rope(q_s, opart, a.q_norm_w, cs, hd, a.strict, red, opart + 2 * hd);
+    head_norm_rope(k_s, opart + hd, a.k_norm_w, cs, hd, a.strict, red, opart + 3 * hd);
+    __syncthreads();
+    if (h % kv_mul == 0)
+        for (int i = tid; i < hd; i += kWG) krow[i] = k_s[i];   // K is rotated in place in the cache
+    if (a.write_q)
+        for (int i = tid; i < hd; i += kWG) a.q[(size_t)h * hd + i] = q_s[i];
+
+    if (a.debug & 8) { if (tid < hd) a.xb[(size_t)h * hd + tid] = q_s[tid]; return; }
+    const float scale = 1.0f / sqrtf((float)hd);  // (head_dim as f32).sqrt().recip()
+    const float* kbase = a.key_cache + (size_t)kvh * hd;
+    const float* vbase = a.value_cache + (size_t)kvh * hd;
+
+    // ---- scores: att[t] = (q . K[t]) * scale                                  layers.rs:391-401
+    if (a.strict) {
+        for (int t = tid; t <= pos; t += kWG) {
+            float dot = -0.0f;
+            if (t == pos) {
+                for (int i = 0; i < hd; ++i) { const float p = q_s[i] * k_s[i]; dot = dot + p; }
+            } else {
+                const float* k = kbase + (size_t)t * kvd;
+                for (int i = 0; i < hd; i += 4) {
+                    const v4f kv = *(const v4f*)(k + i);
+                    float p = q_s[i] * kv.x; dot = dot + p;
+                    p = q_s[i + 1] * kv.y; dot = dot + p;
+                    p = q_s[i + 2] * kv.z; dot = dot + p;
+                    p = q_s[i + 3] * kv.w; dot = dot + p;
+                }
+            }
+            att[t] = dot * scale;
+        }
+    } else {
+        const int lpt = hd >> 2;          // lanes per timestep (float4 each)
+        const int tpw = 64 / lpt;         // timesteps per wave step  (hd <= 256)
+        const int sub = lane / lpt, li = lane % lpt;
+        const v4f qv = *(const v4f*)(q_s + 4 * li);
+        for (int t0 = wave * tpw; t0 <= pos; t0 += kWaves * tpw) {
+            const int t = t0 + sub;
+            float p = 0.0f;
+            if (t <= pos) {
+                v4f kv;
+                if (t == pos) kv = *(const v4f*)(k_s + 4 * li);
+                else kv = *(const v4f*)(kbase + (size_t)t * kvd + 4 * li);
+                p = qv.x * kv.x;
+                p = p + qv.y * kv.y;
+                p = p + qv.z * kv.z;
+                p = p + qv.w * kv.w;
+            }
+            p = group_sum_f32(p, lpt);
+            if (t <= pos && li == 0) att[t] = p * scale;
+        }
+    }
+    __syncthreads();
+
+    // ---- softmax                                                              layers.rs:495-506
+    float m = -__builtin_inff();
+    for (int t = tid; t <= pos; t += kWG) m = fmaxf(m, att[t]);
+    m = block_max(m, red);
+    float part = 0.0f;
+    for (int t = tid; t <= pos; t += kWG) {
+        const float e = q3_expf(att[t] - m);
+        att[t] = e;
+        part = part + e;
+    }
+    float sum;
+    if (a.strict) {
+        __syncthreads();
+        const int np = pos + 1, nq4 = (((size_t)att & 15) == 0) ? (np >> 2) : 0;
+        sum = seq_chain(-0.0f, (const v4f*)att, nq4);
+        for (int t = nq4 << 2; t < np; ++t) sum = sum + att[t];
+    } else {
+        sum = block_sum_fast(part, red);
+    }
+    const float inv = 1.0f / sum;
+    __syncthreads();
+    for (int t = tid; t <= pos; t += kWG) att[t] = att[t] * inv;
+    __syncthreads();
+
+    // ---- xb = sum_t att[t] * V[t]                                              layers.rs:406-417
+    float* out = a.xb + (size_t)h * hd;
+    if (a.strict) {
+        for (int i = tid; i < hd; i += kWG) {
+            float o = 0.0f;  // fill(0.0)
+            for (int t = 0; t <= pos; ++t) {
+                const float p = att[t] * vbase[(size_t)t * kvd + i];
+                o = o + p;
+            }
+            out[i] = o;
+        }
+    } else {
+        const int lpt = hd >> 2, tpw = 64 / lpt;
+        const int sub = lane / lpt, li = lane % lpt;
+        v4f o = {0.f, 0.f, 0.f, 0.f};
+        for (int t0 = wave * tpw; t0 <= pos; t0 += kWaves * tpw) {
+            const int t = t0 + sub;
+            if (t <= pos) {
+                const float w = att[t];
+                const v4f vv = *(const v4f*)(vbase + (size_t)t * kvd + 4 * li);
+                o.x = o.x + w * vv.x;
+                o.y = o.y + w * vv.y;
+                o.z = o.z + w * vv.z;
+                o.w = o.w + w * vv.w;
+            }
+        }
+        // combine the tpw sub-groups of the wave (lanes with equal li), then the waves
+        for (int msk = lpt; msk < 64; msk <<= 1) {
+            o.x += __shfl_xor(o.x, msk);
+            o.y += __shfl_xor(o.y, msk);
+            o.z += __shfl_xor(o.z, msk);
+            o.w += __shfl_xor(o.w, msk);
+        }
+        if (sub == 0) *(v4f*)(opart + wave * hd + 4 * li) = o;
+        __syncthreads();
+        for (int i = tid; i < hd; i += kWG) {
+            float r = opart[i];
+            for (int w = 1; w < kWaves; ++w) r = r + opart[w * hd + i];
+            out[i] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bookkeeping: consume the argmax cell, advance (token, pos, step)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_next(State* st, int32_t* out_tokens, int out_cap) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int idx = (int)(unsigned)(st->argmax & 0xffffffffull);
+        if (st->step < out_cap) out_tokens[st->step] = idx;
+        st->token = idx;
+        st->pos = st->pos + 1;
+        st->step = st->step + 1;
+        st->argmax = 0ull;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stand-alone operator kernels (operator-level C ABI; same device functions as above)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWG) void k_op_quantize(int8_t* q, float* s, const float* x, int n, int group) {
+    // one workgroup; grid-strides over float4 slots
+    const int nv = n >> 2, glanes = group >> 2;
+    for (int v0 = 0; v0 < nv; v0 += kWG) {
+        const int v = v0 + threadIdx.x;
+        const bool valid = v < nv;
+        v4f y = {0.f, 0.f, 0.f, 0.f};
+        if (valid) y = ((const v4f*)x)[v];
+        quantize4_to_lds(y, v, glanes, valid, q, s);
+    }
+}
+
+__global__ void k_op_dequantize(const int8_t* q, const float* s, float* x, size_t n, int group) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        x[i] = (float)q[i] * s[i / (size_t)group];   // tensor.rs:76-79
+}
+
+__global__ __launch_bounds__(kWG) void k_op_rmsnorm(float* out, const float* in, const float* w, int n, int strict) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sq = (float*)smem_raw;               // term_floats(n)
+    float* red = sq + term_floats(n);
+    float part = 0.0f;
+    for (int i = threadIdx.x; i < n; i += kWG) {
+        const float v = in[i];
+        sq[term_index(i, n)] = v * v;
+        part = part + v * v;
+    }
+    float ss;
+    if (strict) {
+        __syncthreads();
+        ss = seq_sum_terms(sq, n);
+    } else {
+        ss = block_sum_fast(part, red);
+    }
+    const float f = 1.0f / sqrtf(ss / (float)n + kEps);
+    for (int i = threadIdx.x; i < n; i += kWG) out[i] = w[i] * (f * in[i]);
+}
+
+__global__ __launch_bounds__(kWG) void k_op_softmax(float* x, int n, int strict) {
+    __shared__ float red[64];
+    float m = -__builtin_inff();
+    for (int t = threadIdx.x; t < n; t += kWG) m = fmaxf(m, x[t]);
+    m = block_max(m, red);
+    float part = 0.0f;
+    for (int t = threadIdx.x; t < n; t += kWG) {
+        const float e = q3_expf(x[t] - m);
+        x[t] = e;
+        part = part + e;
+    }
+    float sum;
+    if (strict) {
+        __syncthreads();
+        sum = -0.0f;
+        for (int t = 0; t < n; ++t) sum = sum + x[t];
+    } else {
+        sum = block_sum_fast(part, red);
+    }
+    const float inv = 1.0f / sum;
+    __syncthreads();
+    for (int t = threadIdx.x; t < n; t += kWG) x[t] = x[t] * inv;
+}
+
+__global__ void k_op_swiglu(float* hb, const float* hb2, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float g = hb[i];
+        const float den = 1.0f + q3_expf(-g);
+        const float sw = g * (1.0f / den);
+        hb[i] = sw * hb2[i];
+    }
+}
+
+__global__ void k_op_expf(float* x, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        x[i] = q3_expf(x[i]);
+}
+
+__global__ __launch_bounds__(kWG) void k_op_argmax(const float* logits, size_t n, unsigned long long* cell) {
+    unsigned long long best = 0ull;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long key = ((unsigned long long)total_order_key(logits[i]) << 32) | (unsigned)i;
+        best = key > best ? key : best;
+    }
+    for (int m = 1; m < 64; m <<= 1) {
+        const unsigned lo = __shfl_xor((unsigned)best, m);
+        const unsigned hi = __shfl_xor((unsigned)(best >> 32), m);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        best = o > best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0 && best != 0ull) atomicMax(cell, best);
+}
+
+}  // namespace q3
