@@ -182,6 +182,9 @@ struct q3_engine {
     State* d_state = nullptr;
     int32_t* d_out_tokens = nullptr;
     int out_cap = 0;
+    unsigned long long* d_stamps = nullptr;   // developer timeline (Q3_STAMPS=1)
+    unsigned long long* d_argmax_slots = nullptr;
+    int n_argmax_slots = 0;
     // pinned host staging
     float* h_logits = nullptr;
     State* h_state = nullptr;
@@ -205,7 +208,8 @@ void launch_one(const Launch& L, q3_engine* e) {
     if (L.is_attn) {
         hipLaunchKernelGGL(k_attn, dim3(L.grid), dim3(kWG), L.smem, e->stream, L.aa);
     } else if (L.is_next) {
-        hipLaunchKernelGGL(k_next, dim3(1), dim3(64), 0, e->stream, e->d_state, e->d_out_tokens, e->out_cap);
+        hipLaunchKernelGGL(k_next, dim3(1), dim3(kWG), 0, e->stream, e->d_state, e->d_argmax_slots, e->n_argmax_slots,
+                           e->d_out_tokens, e->out_cap);
     } else {
         hipLaunchKernelGGL(L.fn, dim3(L.grid), dim3(kWG), L.smem, e->stream, L.ga);
     }
@@ -247,7 +251,7 @@ GemvShape plan_gemv(int units, int n, int G, bool swiglu, int row_align, int n_c
 void q3_engine::release() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (graph) (void)hipGraphDestroy(graph);
-    void* dptrs[] = {d_blob, d_x, d_q, d_kraw, d_xb, d_hb, d_logits, d_tap, d_key, d_value, d_rope, d_att, d_state, d_out_tokens};
+    void* dptrs[] = {d_argmax_slots, d_stamps, d_blob, d_x, d_q, d_kraw, d_xb, d_hb, d_logits, d_tap, d_key, d_value, d_rope, d_att, d_state, d_out_tokens};
     for (void* p : dptrs)
         if (p) (void)hipFree(p);
     if (h_logits) (void)hipHostFree(h_logits);
@@ -414,11 +418,15 @@ int q3_engine::build_plan() {
     const int dim = cfg.dim, L = cfg.n_layers, hd = cfg.head_dim, V = cfg.vocab_size, H = cfg.hidden_dim;
     const int G = cfg.group_size, ahd = cfg.n_heads * hd, kvd = cfg.n_kv_heads * hd, S = cfg.seq_len;
     const int strict = (flags & Q3_FLAG_FAST) ? 0 : 1;
-    const int small_cap = env_int("Q3_WG_PER_CU_SMALL", 1);
+    const int small_cap = env_int("Q3_WG_PER_CU_SMALL", 2);
     const int big_cap = env_int("Q3_WG_PER_CU_LMHEAD", 4);
-    const int att_lds_max = env_int("Q3_ATT_LDS_MAX", 8192);
+    const int att_lds_max = env_int("Q3_ATT_LDS_MAX", 4096);
 
     if (S > att_lds_max) HIP_TRY(hipMalloc((void**)&d_att, 4 * (size_t)cfg.n_heads * S));
+    if (env_int("Q3_STAMPS", 0)) {
+        HIP_TRY(hipMalloc((void**)&d_stamps, 8 * 8 * (size_t)(5 * L + 4)));
+        HIP_TRY(hipMemset(d_stamps, 0, 8 * 8 * (size_t)(5 * L + 4)));
+    }
 
     auto base_args = [&](int n) {
         GemvArgs a{};
@@ -431,15 +439,17 @@ int q3_engine::build_plan() {
         return a;
     };
     int rc;
+    const int alias0 = env_int("Q3_DEBUG_ALIAS_LAYER0", 0);   // experiment: every layer streams layer 0's weights
     for (int l = 0; l < L; ++l) {
         const size_t kv_off = (size_t)l * S * kvd;
+        const int lw = alias0 ? 0 : l;
         {   // xb = RMSNorm_att(x); xq = quantize(xb); q,k,v = W{q,k,v} xq         qwen3.rs:134-136, layers.rs:334-337
             Launch Ln;
             Ln.fam = F_QKV;
             GemvArgs a = base_args(dim);
-            a.seg[0] = Seg{wq[l].q, wq[l].s, d_q, ahd, 0};
-            a.seg[1] = Seg{wk[l].q, wk[l].s, d_kraw, kvd, 0};
-            a.seg[2] = Seg{wv[l].q, wv[l].s, d_value + kv_off, kvd, kvd};
+            a.seg[0] = Seg{wq[lw].q, wq[lw].s, d_q, ahd, 0};
+            a.seg[1] = Seg{wk[lw].q, wk[lw].s, d_kraw, kvd, 0};
+            a.seg[2] = Seg{wv[lw].q, wv[lw].s, d_value + kv_off, kvd, kvd};
             a.total_rows = ahd + 2 * kvd;
             for (int k = 0; k < 2; ++k) {
                 a.qkv_dw[k] = (const char*)a.seg[k + 1].wq - (const char*)a.seg[k].wq;
@@ -463,6 +473,7 @@ int q3_engine::build_plan() {
             Ln.ga = a;
             if (!Ln.fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel instantiated for this tile shape");
             if ((rc = set_max_smem((const void*)Ln.fn, Ln.smem))) return rc;
+            if (d_stamps) { Ln.ga.stamps = d_stamps + 8 * plan.size(); Ln.ga.stamp_block = env_int("Q3_STAMP_BLOCK", 7); }
             plan.push_back(Ln);
         }
         {   // QK-norm + RoPE + attention                                        layers.rs:346-419
@@ -498,7 +509,7 @@ int q3_engine::build_plan() {
             Launch Ln;
             Ln.fam = F_WO;
             GemvArgs a = base_args(ahd);
-            a.seg[0] = Seg{wo[l].q, wo[l].s, d_x, dim, 0};
+            a.seg[0] = Seg{wo[lw].q, wo[lw].s, d_x, dim, 0};
             a.total_rows = dim;
             a.in = d_xb;
             const GemvShape gs = plan_gemv(dim, ahd, G, false, 1, n_cu, small_cap);
@@ -509,14 +520,15 @@ int q3_engine::build_plan() {
             Ln.ga = a;
             if (!Ln.fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel instantiated for this tile shape");
             if ((rc = set_max_smem((const void*)Ln.fn, Ln.smem))) return rc;
+            if (d_stamps) { Ln.ga.stamps = d_stamps + 8 * plan.size(); Ln.ga.stamp_block = env_int("Q3_STAMP_BLOCK", 7); }
             plan.push_back(Ln);
         }
         {   // xb = RMSNorm_ffn(x); xq = quantize(xb); hb = silu(W1 xq) * (W3 xq)   qwen3.rs:159-161, layers.rs:468-475
             Launch Ln;
             Ln.fam = F_W13;
             GemvArgs a = base_args(dim);
-            a.seg[0] = Seg{w1[l].q, w1[l].s, d_hb, H, 0};
-            a.seg[1] = Seg{w3[l].q, w3[l].s, nullptr, H, 0};
+            a.seg[0] = Seg{w1[lw].q, w1[lw].s, d_hb, H, 0};
+            a.seg[1] = Seg{w3[lw].q, w3[lw].s, nullptr, H, 0};
             a.total_rows = 2 * H;
             a.norm_w = rms_ffn + (size_t)l * dim;
             a.in = d_x;
@@ -528,13 +540,14 @@ int q3_engine::build_plan() {
             Ln.ga = a;
             if (!Ln.fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel instantiated for this tile shape");
             if ((rc = set_max_smem((const void*)Ln.fn, Ln.smem))) return rc;
+            if (d_stamps) { Ln.ga.stamps = d_stamps + 8 * plan.size(); Ln.ga.stamp_block = env_int("Q3_STAMP_BLOCK", 7); }
             plan.push_back(Ln);
         }
         {   // hq = quantize(hb); x += W2 hq                                      layers.rs:478-479, qwen3.rs:175
             Launch Ln;
             Ln.fam = F_W2;
             GemvArgs a = base_args(H);
-            a.seg[0] = Seg{w2[l].q, w2[l].s, d_x, dim, 0};
+            a.seg[0] = Seg{w2[lw].q, w2[lw].s, d_x, dim, 0};
             a.total_rows = dim;
             a.in = d_hb;
             const GemvShape gs = plan_gemv(dim, H, G, false, 1, n_cu, small_cap);
@@ -545,6 +558,7 @@ int q3_engine::build_plan() {
             Ln.ga = a;
             if (!Ln.fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel instantiated for this tile shape");
             if ((rc = set_max_smem((const void*)Ln.fn, Ln.smem))) return rc;
+            if (d_stamps) { Ln.ga.stamps = d_stamps + 8 * plan.size(); Ln.ga.stamp_block = env_int("Q3_STAMP_BLOCK", 7); }
             plan.push_back(Ln);
         }
     }
@@ -558,6 +572,10 @@ int q3_engine::build_plan() {
         a.in = d_x;
         a.tap_out = d_tap;
         const GemvShape gs = plan_gemv(V, dim, G, false, 1, n_cu, big_cap);
+        n_argmax_slots = (int)gs.grid;
+        HIP_TRY(hipMalloc((void**)&d_argmax_slots, 8 * (size_t)n_argmax_slots));
+        HIP_TRY(hipMemset(d_argmax_slots, 0, 8 * (size_t)n_argmax_slots));
+        a.argmax_slots = d_argmax_slots;
         Ln.fn = pick<PRO_NORM, EPI_LOGITS>(G, gs.RU, gs.JU);
         a.vr = gs.RU;
         Ln.grid = gs.grid;
@@ -578,7 +596,8 @@ int q3_engine::build_plan() {
 
 int q3_engine::capture() {
     HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-    for (const Launch& L : plan) launch_one(L, this);
+    const int dbl = env_int("Q3_DEBUG_DOUBLE", 0);   // experiment: run every kernel twice (I-cache warm second run)
+    for (const Launch& L : plan) { launch_one(L, this); if (dbl && !L.is_next) launch_one(L, this); }
     HIP_TRY(hipStreamEndCapture(stream, &graph));
     HIP_TRY(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
     return Q3_OK;
@@ -705,6 +724,19 @@ int q3_generate_greedy(q3_engine* e, size_t first_token, size_t first_pos, size_
     HIP_TRY(hipMemcpyAsync(e->h_tokens, e->d_out_tokens, 4 * n_tokens, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     clock_gettime(CLOCK_MONOTONIC, &t2);
+    if (e->d_stamps) {
+        const size_t nl = e->plan.size();
+        std::vector<unsigned long long> h(8 * nl);
+        HIP_TRY(hipMemcpy(h.data(), e->d_stamps, 8 * 8 * nl, hipMemcpyDeviceToHost));
+        double acc[F_COUNT][8] = {}; int cnt[F_COUNT] = {};
+        for (size_t i = 0; i < nl; ++i) {
+            if (e->plan[i].is_attn || e->plan[i].is_next || h[8 * i] == 0) continue;
+            for (int k = 1; k < 6; ++k) acc[e->plan[i].fam][k] += (double)(h[8 * i + k] - h[8 * i]);
+            cnt[e->plan[i].fam]++;
+        }
+        for (int f = 0; f < F_COUNT; ++f)
+            if (cnt[f]) fprintf(stderr, "[q3 stamps] %-8s n=%d  issue %.0f  prologue %.0f  tile %.0f  finish %.0f  end %.0f  (s_memtime ticks after entry)\n", kFamilyNames[f], cnt[f], acc[f][1] / cnt[f], acc[f][2] / cnt[f], acc[f][3] / cnt[f], acc[f][4] / cnt[f], acc[f][5] / cnt[f]);
+    }
     if (getenv("Q3_DEBUG_TIMING"))
         fprintf(stderr, "[q3] generate_greedy n=%zu enqueue %.1f us, drain %.1f us\n", n_tokens,
                 (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3,
@@ -939,7 +971,7 @@ int q3_op_attention(float* xb, float* q, float* key_cache_layer, const float* va
             tab[p * head_dim + 2 * i + 1] = sinf(angle);
         }
     if ((rc = drope.upload(tab.data(), 4 * tab.size()))) return rc;
-    const bool att_global = seq_len > 8192;
+    const bool att_global = seq_len > 4096;
     if (att_global && (rc = datt.alloc(4 * n_heads * seq_len))) return rc;
     AttnArgs a{};
     a.q = dq.as<float>();
@@ -967,6 +999,70 @@ int q3_op_attention(float* xb, float* q, float* key_cache_layer, const float* va
     HIP_TRY(hipMemcpy(q, dq.p, 4 * ahd, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(key_cache_layer + pos * kvd, (float*)dk.p + pos * kvd, 4 * kvd, hipMemcpyDeviceToHost));
     return Q3_OK;
+}
+
+/* developer micro-benchmark (not part of the drop-in surface): average device time of the stand-alone
+ * W8A8 GEMV (PRO_PREQ/EPI_STORE) over `reps` launches on random weights resident in HBM.  ru/ju/wg_per_cu
+ * <= 0 pick the planner's choice.  Distinct weight copies are cycled so nothing stays cache-resident. */
+int q3_dev_bench_gemv(size_t n, size_t d, size_t group_size, int wg_per_cu, int ru, int ju, int reps, int device,
+                      float* avg_us, int32_t* used /*[3]: RU, JU, grid*/) {
+    int rc = op_begin(device);
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    const size_t wbytes = n * d, sbytes = 4 * (n * d / group_size);
+    size_t copies = (512ull << 20) / (wbytes + sbytes) + 1;
+    if (copies > 16) copies = 16;
+    if (copies < 2) copies = 2;
+    DevBuf dw, ds, dxq, dxs, dout;
+    if ((rc = dw.alloc(wbytes * copies)) || (rc = ds.alloc(sbytes * copies)) || (rc = dxq.alloc(n)) ||
+        (rc = dxs.alloc(4 * (n / group_size))) || (rc = dout.alloc(4 * d)))
+        return rc;
+    HIP_TRY(hipMemset(dw.p, 0x11, wbytes * copies));
+    HIP_TRY(hipMemset(ds.p, 0, sbytes * copies));
+    HIP_TRY(hipMemset(dxq.p, 1, n));
+    HIP_TRY(hipMemset(dxs.p, 0, 4 * (n / group_size)));
+    GemvShape gs = plan_gemv((int)d, (int)n, (int)group_size, false, 1, prop.multiProcessorCount, wg_per_cu > 0 ? wg_per_cu : 4);
+    if (ru > 0) gs.RU = ru;
+    if (ju > 0) gs.JU = ju;
+    if (ru > 0 || ju > 0) {
+        const long nb = ((long)d + gs.RU - 1) / gs.RU;
+        long grid = (nb + kWaves - 1) / kWaves;
+        const long cap = (long)prop.multiProcessorCount * (wg_per_cu > 0 ? wg_per_cu : 4);
+        gs.grid = (unsigned)(grid > cap ? cap : grid);
+    }
+    GemvFn fn = pick<PRO_PREQ, EPI_STORE>((int)group_size, gs.RU, gs.JU);
+    if (!fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel for tile %dx%d", gs.RU, gs.JU);
+    const size_t smem = gemv_smem_bytes((int)n, (int)group_size, gs.RU, false);
+    if ((rc = set_max_smem((const void*)fn, smem))) return rc;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    auto launch = [&](int i) {
+        GemvArgs a{};
+        a.n = (int)n;
+        a.group = (int)group_size;
+        a.vr = gs.RU;
+        a.seg[0] = Seg{dw.as<int8_t>() + (size_t)(i % copies) * wbytes, (const float*)((char*)ds.p + (size_t)(i % copies) * sbytes),
+                       dout.as<float>(), (int)d, 0};
+        a.total_rows = (int)d;
+        a.pre_q = dxq.as<int8_t>();
+        a.pre_s = dxs.as<float>();
+        hipLaunchKernelGGL(fn, dim3(gs.grid), dim3(kWG), smem, 0, a);
+    };
+    for (int i = 0; i < 3; ++i) launch(i);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) launch(i);
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (avg_us) *avg_us = ms * 1e3f / reps;
+    if (used) { used[0] = gs.RU; used[1] = gs.JU; used[2] = (int)gs.grid; }
+    return op_end();
 }
 
 int q3_op_argmax(const float* logits, size_t n, int32_t* index, int device) {

@@ -182,6 +182,8 @@ struct GemvArgs {
     int total_rows;      // sum of seg rows (EPI_SWIGLU: hidden units * 2 handled via seg[0],seg[1])
     int strict;
     int debug;           // developer ablation bits (Q3_ABLATE): 1 skip prologue math, 2 skip tiles, 4 skip ordered sum
+    unsigned long long* stamps;  // developer timeline: 8 s_memtime stamps written by (block stamp_block, wave 0)
+    int stamp_block;
     // prologue inputs
     const float* in;       // PRO_QUANT: f32[n]; PRO_NORM: x f32[n]
     const float* norm_w;   // PRO_NORM*: RMSNorm weight f32[n]
@@ -191,7 +193,8 @@ struct GemvArgs {
     const float* emb_s;
     float* x_out;          // PRO_EMBED_NORM: residual stream x (written by workgroup 0)
     float* tap_out;        // PRO_NORM: optional copy of the normalised vector (workgroup 0)
-    State* st;             // token / pos / argmax cell
+    State* st;             // token / pos
+    unsigned long long* argmax_slots;  // EPI_LOGITS: one (key<<32|index) per workgroup
     int seq_len;
 };
 
@@ -572,9 +575,17 @@ __device__ __forceinline__ float ordered_row_sum(const float* t, int ng) {
     return acc;
 }
 
+__device__ __forceinline__ void stamp(const GemvArgs& a, int idx) {
+    if (a.stamps != nullptr && (int)blockIdx.x == a.stamp_block && threadIdx.x == 0) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        a.stamps[idx] = t;
+    }
+}
+
 template <int PRO, int EPI, int LPG_T, int RU, int JU>
 __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    stamp(a, 0);
     constexpr bool kStage = (PRO == PRO_NORM || PRO == PRO_EMBED_NORM);
     constexpr int HU = (EPI == EPI_SWIGLU) ? (RU / 2) : RU;   // rows per run
     static_assert(EPI != EPI_SWIGLU || RU >= 2, "SwiGLU tiles hold a w1 and a w3 row");
@@ -712,19 +723,23 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
     RA = batch_rows(min(cb, nb - 1));         // (idle waves re-read a valid batch; nothing is stored)
     load_tile(TA, RA, 0);                     // ... then the first weight tile ...
     __builtin_amdgcn_sched_barrier(0);
+    stamp(a, 1);
     if (a.debug & 1) {
         for (int i = threadIdx.x; i < (a.n >> 2); i += kWG) ((int*)sm.xq)[i] = 0x01010101;
         for (int i = threadIdx.x; i < a.n / a.group; i += kWG) sm.xs[i] = 1.0f;
         __syncthreads();
     } else
     gemv_prologue_finish<PRO>(a, sm, pr);     // ... and norm + quantize run under the weight loads
+    stamp(a, 2);
     if (any && !(a.debug & 2)) {
         for (;;) {
             int nb_ = cb, njt_ = cjt + 1;
             if (njt_ == njt) { njt_ = 0; nb_ = cb + nwaves; }
             if (nb_ >= nb) {
                 compute_tile(TA, RA, cjt);
+                stamp(a, 3);
                 if (cjt == njt - 1) finish(RA);
+                stamp(a, 4);
                 break;
             }
             if (njt_ == 0) RB = batch_rows(nb_); else RB = RA;
@@ -747,15 +762,25 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
             cb = nb_; cjt = njt_;
         }
     }
+    stamp(a, 5);
     if (EPI == EPI_LOGITS) {
-        // Sampler::sample_argmax (sampler.rs:57-59): equal keys -> larger index wins == last maximum
+        // Sampler::sample_argmax (sampler.rs:57-59): equal keys -> larger index wins == last maximum.
+        // wave max -> workgroup max (LDS) -> one plain store per workgroup; k_next reduces the slots
+        // (4096 same-address atomics would serialise at ~12 ns each).
         for (int m = 1; m < 64; m <<= 1) {
             const unsigned lo = __shfl_xor((unsigned)best, m);
             const unsigned hi = __shfl_xor((unsigned)(best >> 32), m);
             const unsigned long long o = ((unsigned long long)hi << 32) | lo;
             best = o > best ? o : best;
         }
-        if (lane == 0 && best != 0ull) atomicMax(&a.st->argmax, best);
+        unsigned long long* wred = (unsigned long long*)sm.red;
+        if (lane == 0) wred[wave] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long b = wred[0];
+            for (int w = 1; w < kWaves; ++w) b = wred[w] > b ? wred[w] : b;
+            a.argmax_slots[blockIdx.x] = b;
+        }
     }
 }
 
@@ -782,123 +807,187 @@ struct AttnArgs {
     int debug;                // ablation: 8 = return right after the q/k norm+rope
 };
 
+// LDS plan of k_attn (floats): q_s[hd] k_s[hd] raw[2hd] sq[2hd] opart[kWaves*hd] red[64] att[att_lds]
+//                              kbuf[TCH][hd+4] vbuf[TCH][hd]
+// K and V rows of a chunk of TCH timesteps are staged in LDS (K rows padded by 4 floats so that the
+// per-timestep readers hit distinct banks); chunk 0 of both is requested at kernel entry, before q exists.
+constexpr int kKPad = 4;
+__host__ __device__ inline int attn_tch(int hd) { return hd <= 128 ? 128 : 16384 / hd; }
 __host__ __device__ inline size_t attn_smem_bytes(int hd, int att_lds_floats) {
-    // q[hd] kcur[hd] opart[kWaves][hd] red[64] att[att_lds_floats]
-    return 4 * ((size_t)hd * (2 + kWaves) + 64 + (size_t)att_lds_floats);
+    const int tch = attn_tch(hd);
+    return 4 * ((size_t)hd * (6 + kWaves) + 64 + (size_t)((att_lds_floats + 3) & ~3) + (size_t)tch * (2 * hd + kKPad));
 }
 
-// RMSNorm over hd values followed by RoPE, result in dst (LDS).  src: hd raw values in LDS.
-__device__ __forceinline__ void head_norm_rope(float* dst, const float* src, const float* w, const float* cs,
-                                               int hd, int strict, float* red, float* sq) {
-    const int tid = threadIdx.x;
+// one WAVE: RMSNorm over hd raw values (LDS) followed by RoPE -> dst (LDS).  layers.rs:109-119,173-185
+__device__ __forceinline__ void wave_norm_rope(float* dst, const float* src, float* sq, const float* w, const float* cs,
+                                               int hd, int strict) {
+    const int lane = threadIdx.x & 63;
     float ss;
     if (strict) {
-        for (int i = tid; i < hd; i += kWG) sq[i] = src[i] * src[i];
-        __syncthreads();
-        ss = seq_sum_terms(sq, hd);
+        for (int i = lane; i < hd; i += 64) sq[i] = src[i] * src[i];
+        wave_lds_sync();
+        ss = seq_chain(-0.0f, (const v4f*)sq, hd >> 2);   // hd % 8 == 0
     } else {
         float p = 0.0f;
-        for (int i = tid; i < hd; i += kWG) p = p + src[i] * src[i];
-        ss = block_sum_fast(p, red);
+        for (int i = lane; i < hd; i += 64) p = p + src[i] * src[i];
+        ss = group_sum_f32(p, 64);
     }
     const float f = 1.0f / sqrtf(ss / (float)hd + kEps);
     const int half = hd >> 1;
-    for (int i = tid; i < half; i += kWG) {
+    for (int i = lane; i < half; i += 64) {
         const float xv = w[i] * (f * src[i]);
         const float yv = w[i + half] * (f * src[i + half]);
-        const float c = cs[2 * i], s = cs[2 * i + 1];
-        const float a0 = xv * c, b0 = yv * s;
-        const float a1 = xv * s, b1 = yv * c;
+        const float c = cs[2 * i], sn = cs[2 * i + 1];
+        const float a0 = xv * c, b0 = yv * sn;
+        const float a1 = xv * sn, b1 = yv * c;
         dst[i] = a0 - b0;            // layers.rs:181-182
         dst[i + half] = a1 + b1;
+    }
+}
+
+// A chunk of <= TCH timesteps of one kv head is tch*hd <= 16384 floats = 16 float4 per thread: all 16
+// loads are issued at once (one round trip) and written to LDS later, so other work overlaps the flight.
+constexpr int kStageSlots = 16;
+struct StageRegs { v4f v[kStageSlots]; };
+__device__ __forceinline__ void stage_issue(StageRegs& sr, const float* gbase, size_t kvd, int t0, int cnt, int hd) {
+    const int q4 = hd >> 2;                 // float4 per row
+    const int total = cnt * q4;
+#pragma unroll
+    for (int u = 0; u < kStageSlots; ++u) {
+        const int idx = min((int)threadIdx.x + u * kWG, total - 1);   // tail slots re-read the last float4
+        const int r = idx / q4, c = idx - r * q4;
+        sr.v[u] = *(const v4f*)(gbase + (size_t)(t0 + r) * kvd + 4 * c);
+    }
+}
+// rows land at lds + r*ld; `skip` (absolute timestep or -1) is left untouched
+__device__ __forceinline__ void stage_commit(const StageRegs& sr, float* lds, int ld, int t0, int cnt, int hd, int skip) {
+    const int q4 = hd >> 2;
+    const int total = cnt * q4;
+#pragma unroll
+    for (int u = 0; u < kStageSlots; ++u) {
+        const int idx = (int)threadIdx.x + u * kWG;
+        if (idx < total) {
+            const int r = idx / q4, c = idx - r * q4;
+            if (t0 + r != skip) *(v4f*)(lds + r * ld + 4 * c) = sr.v[u];
+        }
     }
 }
 
 __global__ __launch_bounds__(kWG) void k_attn(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int hd = a.hd;
+    const int tch = attn_tch(hd);
+    const int kld = hd + kKPad;
     float* q_s = (float*)smem_raw;
     float* k_s = q_s + hd;
-    float* opart = k_s + hd;
-    float* red = opart + kWaves * hd;
+    float* raw = k_s + hd;            // [2*hd] raw q | raw k
+    float* sq = raw + 2 * hd;         // [2*hd]
+    float* opart = sq + 2 * hd;       // [kWaves*hd]
+    float* red = opart + kWaves * hd; // [64]
     float* att_l = red + 64;
+    const int att_lds = a.att_global ? 0 : a.seq_len;
+    float* kbuf = att_l + ((att_lds + 3) & ~3);    // [tch][kld]
+    float* vbuf = kbuf + tch * kld;   // [tch][hd]
 
     const int h = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kv_mul = a.n_heads / a.n_kv_heads;
     const int kvh = h / kv_mul;
-    const int kvd = a.n_kv_heads * hd;
+    const size_t kvd = (size_t)a.n_kv_heads * hd;
     const int pos = a.pos_override >= 0 ? a.pos_override : a.st->pos;
     float* att = a.att_global ? a.att_global + (size_t)h * a.seq_len : att_l;
     const float* cs = a.rope + (size_t)pos * hd;  // hd/2 (cos,sin) pairs
-
-    // ---- stage raw q head and raw k row (current position) into LDS
-    float* krow = a.key_cache + (size_t)pos * kvd + (size_t)kvh * hd;
-    for (int i = tid; i < hd; i += kWG) {
-        opart[i] = a.q[(size_t)h * hd + i];
-        opart[hd + i] = a.k_raw[(size_t)kvh * hd + i];
-    }
-    __syncthreads();
-    head_norm_rope(q_s, opart, a.q_norm_w, cs, hd, a.strict, red, opart + 2 * hd);
-    head_norm_rope(k_s, opart + hd, a.k_norm_w, cs, hd, a.strict, red, opart + 3 * hd);
-    __syncthreads();
-    if (h % kv_mul == 0)
-        for (int i = tid; i < hd; i += kWG) krow[i] = k_s[i];   // K is rotated in place in the cache
-    if (a.write_q)
-        for (int i = tid; i < hd; i += kWG) a.q[(size_t)h * hd + i] = q_s[i];
-
-    if (a.debug & 8) { if (tid < hd) a.xb[(size_t)h * hd + tid] = q_s[tid]; return; }
-    const float scale = 1.0f / sqrtf((float)hd);  // (head_dim as f32).sqrt().recip()
     const float* kbase = a.key_cache + (size_t)kvh * hd;
     const float* vbase = a.value_cache + (size_t)kvh * hd;
+    const int np = pos + 1;
+    const int nch = (np + tch - 1) / tch;
+
+    // ---- raw q head / raw k row first, then chunk 0 of K and V: everything is in flight before q exists
+    float rq = 0.f, rk = 0.f;
+    if (tid < hd) {
+        rq = a.q[(size_t)h * hd + tid];
+        rk = a.k_raw[(size_t)kvh * hd + tid];
+    }
+    const int cnt0 = min(tch, np);
+    StageRegs sk, sv;
+    __builtin_amdgcn_sched_barrier(0);
+    stage_issue(sk, kbase, kvd, 0, cnt0, hd);
+    stage_issue(sv, vbase, kvd, 0, cnt0, hd);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid < hd) {
+        raw[tid] = rq;
+        raw[hd + tid] = rk;
+    }
+    __syncthreads();
+    // ---- waves 0/1: QK-RMSNorm + RoPE of q / k (layers.rs:346-372) under the K/V loads
+    if (wave == 0) wave_norm_rope(q_s, raw, sq, a.q_norm_w, cs, hd, a.strict);
+    else if (wave == 1) wave_norm_rope(k_s, raw + hd, sq + hd, a.k_norm_w, cs, hd, a.strict);
+    stage_commit(sk, kbuf, kld, 0, cnt0, hd, pos);
+    stage_commit(sv, vbuf, hd, 0, cnt0, hd, -1);
+    __syncthreads();
+    float* krow = a.key_cache + (size_t)pos * kvd + (size_t)kvh * hd;
+    if (h % kv_mul == 0)
+        for (int i = tid; i < hd; i += kWG) krow[i] = k_s[i];   // K is normalised + rotated in place in the cache
+    if (a.write_q)
+        for (int i = tid; i < hd; i += kWG) a.q[(size_t)h * hd + i] = q_s[i];
+    if (a.debug & 8) { if (tid < hd) a.xb[(size_t)h * hd + tid] = q_s[tid]; return; }
+
+    const float scale = 1.0f / sqrtf((float)hd);  // (head_dim as f32).sqrt().recip()
 
     // ---- scores: att[t] = (q . K[t]) * scale                                  layers.rs:391-401
-    if (a.strict) {
-        for (int t = tid; t <= pos; t += kWG) {
-            float dot = -0.0f;
-            if (t == pos) {
-                for (int i = 0; i < hd; ++i) { const float p = q_s[i] * k_s[i]; dot = dot + p; }
-            } else {
-                const float* k = kbase + (size_t)t * kvd;
+    for (int c = 0; c < nch; ++c) {
+        const int t0 = c * tch, cnt = min(tch, np - t0);
+        if (c > 0) {
+            stage_issue(sk, kbase, kvd, t0, cnt, hd);
+            __syncthreads();
+            stage_commit(sk, kbuf, kld, t0, cnt, hd, pos);
+        }
+        if (pos >= t0 && pos < t0 + cnt)      // the current position's K comes from this kernel, not the cache
+            for (int i = tid; i < hd; i += kWG) kbuf[(pos - t0) * kld + i] = k_s[i];
+        __syncthreads();
+        if (a.strict) {
+            for (int t = tid; t < cnt; t += kWG) {
+                const float* k = kbuf + t * kld;
+                float dot = -0.0f;
+#pragma unroll 4
                 for (int i = 0; i < hd; i += 4) {
                     const v4f kv = *(const v4f*)(k + i);
-                    float p = q_s[i] * kv.x; dot = dot + p;
-                    p = q_s[i + 1] * kv.y; dot = dot + p;
-                    p = q_s[i + 2] * kv.z; dot = dot + p;
-                    p = q_s[i + 3] * kv.w; dot = dot + p;
+                    const v4f qv = *(const v4f*)(q_s + i);
+                    float p = qv.x * kv.x; dot = dot + p;
+                    p = qv.y * kv.y; dot = dot + p;
+                    p = qv.z * kv.z; dot = dot + p;
+                    p = qv.w * kv.w; dot = dot + p;
                 }
+                att[t0 + t] = dot * scale;
             }
-            att[t] = dot * scale;
-        }
-    } else {
-        const int lpt = hd >> 2;          // lanes per timestep (float4 each)
-        const int tpw = 64 / lpt;         // timesteps per wave step  (hd <= 256)
-        const int sub = lane / lpt, li = lane % lpt;
-        const v4f qv = *(const v4f*)(q_s + 4 * li);
-        for (int t0 = wave * tpw; t0 <= pos; t0 += kWaves * tpw) {
-            const int t = t0 + sub;
-            float p = 0.0f;
-            if (t <= pos) {
-                v4f kv;
-                if (t == pos) kv = *(const v4f*)(k_s + 4 * li);
-                else kv = *(const v4f*)(kbase + (size_t)t * kvd + 4 * li);
-                p = qv.x * kv.x;
-                p = p + qv.y * kv.y;
-                p = p + qv.z * kv.z;
-                p = p + qv.w * kv.w;
+        } else {
+            const int lpt = hd >> 2;          // lanes per timestep (float4 each)
+            const int tpw = 64 / lpt;         // timesteps per wave step  (hd <= 256)
+            const int sub = lane / lpt, li = lane % lpt;
+            const v4f qv = *(const v4f*)(q_s + 4 * li);
+            for (int tb = wave * tpw; tb < cnt; tb += kWaves * tpw) {
+                const int t = tb + sub;
+                float p = 0.0f;
+                if (t < cnt) {
+                    const v4f kv = *(const v4f*)(kbuf + t * kld + 4 * li);
+                    p = qv.x * kv.x;
+                    p = p + qv.y * kv.y;
+                    p = p + qv.z * kv.z;
+                    p = p + qv.w * kv.w;
+                }
+                p = group_sum_f32(p, lpt);
+                if (t < cnt && li == 0) att[t0 + t] = p * scale;
             }
-            p = group_sum_f32(p, lpt);
-            if (t <= pos && li == 0) att[t] = p * scale;
         }
     }
     __syncthreads();
 
     // ---- softmax                                                              layers.rs:495-506
     float m = -__builtin_inff();
-    for (int t = tid; t <= pos; t += kWG) m = fmaxf(m, att[t]);
+    for (int t = tid; t < np; t += kWG) m = fmaxf(m, att[t]);
     m = block_max(m, red);
     float part = 0.0f;
-    for (int t = tid; t <= pos; t += kWG) {
+    for (int t = tid; t < np; t += kWG) {
         const float e = q3_expf(att[t] - m);
         att[t] = e;
         part = part + e;
@@ -906,7 +995,7 @@ __global__ __launch_bounds__(kWG) void k_attn(const AttnArgs a) {
     float sum;
     if (a.strict) {
         __syncthreads();
-        const int np = pos + 1, nq4 = (((size_t)att & 15) == 0) ? (np >> 2) : 0;
+        const int nq4 = (((size_t)att & 15) == 0) ? (np >> 2) : 0;
         sum = seq_chain(-0.0f, (const v4f*)att, nq4);
         for (int t = nq4 << 2; t < np; ++t) sum = sum + att[t];
     } else {
@@ -914,43 +1003,62 @@ __global__ __launch_bounds__(kWG) void k_attn(const AttnArgs a) {
     }
     const float inv = 1.0f / sum;
     __syncthreads();
-    for (int t = tid; t <= pos; t += kWG) att[t] = att[t] * inv;
+    for (int t = tid; t < np; t += kWG) att[t] = att[t] * inv;
     __syncthreads();
 
     // ---- xb = sum_t att[t] * V[t]                                              layers.rs:406-417
     float* out = a.xb + (size_t)h * hd;
+    float o_s = 0.0f;                       // strict: element tid (fill(0.0) then += in t order)
+    v4f o_f = {0.f, 0.f, 0.f, 0.f};         // default: this lane's partial over its timesteps
+    const int lpt = hd >> 2, tpw = 64 / lpt;
+    const int sub = lane / lpt, li = lane % lpt;
+    for (int c = 0; c < nch; ++c) {
+        const int t0 = c * tch, cnt = min(tch, np - t0);
+        if (c > 0) {
+            stage_issue(sv, vbase, kvd, t0, cnt, hd);
+            __syncthreads();
+            stage_commit(sv, vbuf, hd, t0, cnt, hd, -1);
+            __syncthreads();
+        }
+        if (a.strict) {
+            if (tid < hd) {
+                const float* v = vbuf + tid;
+                const float* w = att + t0;
+                int t = 0;
+                for (; t + 8 <= cnt; t += 8) {
+                    float vv[8], ww[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { vv[u] = v[(t + u) * hd]; ww[u] = w[t + u]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { const float p = ww[u] * vv[u]; o_s = o_s + p; }
+                }
+                for (; t < cnt; ++t) { const float p = w[t] * v[t * hd]; o_s = o_s + p; }
+            }
+        } else {
+            for (int tb = wave * tpw; tb < cnt; tb += kWaves * tpw) {
+                const int t = tb + sub;
+                if (t < cnt) {
+                    const float w = att[t0 + t];
+                    const v4f vv = *(const v4f*)(vbuf + t * hd + 4 * li);
+                    o_f.x = o_f.x + w * vv.x;
+                    o_f.y = o_f.y + w * vv.y;
+                    o_f.z = o_f.z + w * vv.z;
+                    o_f.w = o_f.w + w * vv.w;
+                }
+            }
+        }
+    }
     if (a.strict) {
-        for (int i = tid; i < hd; i += kWG) {
-            float o = 0.0f;  // fill(0.0)
-            for (int t = 0; t <= pos; ++t) {
-                const float p = att[t] * vbase[(size_t)t * kvd + i];
-                o = o + p;
-            }
-            out[i] = o;
-        }
+        if (tid < hd) out[tid] = o_s;
     } else {
-        const int lpt = hd >> 2, tpw = 64 / lpt;
-        const int sub = lane / lpt, li = lane % lpt;
-        v4f o = {0.f, 0.f, 0.f, 0.f};
-        for (int t0 = wave * tpw; t0 <= pos; t0 += kWaves * tpw) {
-            const int t = t0 + sub;
-            if (t <= pos) {
-                const float w = att[t];
-                const v4f vv = *(const v4f*)(vbase + (size_t)t * kvd + 4 * li);
-                o.x = o.x + w * vv.x;
-                o.y = o.y + w * vv.y;
-                o.z = o.z + w * vv.z;
-                o.w = o.w + w * vv.w;
-            }
-        }
         // combine the tpw sub-groups of the wave (lanes with equal li), then the waves
         for (int msk = lpt; msk < 64; msk <<= 1) {
-            o.x += __shfl_xor(o.x, msk);
-            o.y += __shfl_xor(o.y, msk);
-            o.z += __shfl_xor(o.z, msk);
-            o.w += __shfl_xor(o.w, msk);
+            o_f.x += __shfl_xor(o_f.x, msk);
+            o_f.y += __shfl_xor(o_f.y, msk);
+            o_f.z += __shfl_xor(o_f.z, msk);
+            o_f.w += __shfl_xor(o_f.w, msk);
         }
-        if (sub == 0) *(v4f*)(opart + wave * hd + 4 * li) = o;
+        if (sub == 0) *(v4f*)(opart + wave * hd + 4 * li) = o_f;
         __syncthreads();
         for (int i = tid; i < hd; i += kWG) {
             float r = opart[i];
@@ -963,14 +1071,27 @@ __global__ __launch_bounds__(kWG) void k_attn(const AttnArgs a) {
 // ------------------------------------------------------------------------------------------------
 // Bookkeeping: consume the argmax cell, advance (token, pos, step)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_next(State* st, int32_t* out_tokens, int out_cap) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const int idx = (int)(unsigned)(st->argmax & 0xffffffffull);
+__global__ __launch_bounds__(kWG) void k_next(State* st, const unsigned long long* slots, int nslots, int32_t* out_tokens,
+                                              int out_cap) {
+    __shared__ unsigned long long red[kWaves];
+    unsigned long long best = 0ull;
+    for (int i = threadIdx.x; i < nslots; i += kWG) best = slots[i] > best ? slots[i] : best;
+    for (int m = 1; m < 64; m <<= 1) {
+        const unsigned lo = __shfl_xor((unsigned)best, m);
+        const unsigned hi = __shfl_xor((unsigned)(best >> 32), m);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        best = o > best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kWaves; ++w) best = red[w] > best ? red[w] : best;
+        const int idx = (int)(unsigned)(best & 0xffffffffull);
         if (st->step < out_cap) out_tokens[st->step] = idx;
         st->token = idx;
         st->pos = st->pos + 1;
         st->step = st->step + 1;
-        st->argmax = 0ull;
+        st->argmax = best;
     }
 }
 
