@@ -213,6 +213,10 @@ class OracleModel:
             raise IndexError(last_error())
         return np.ctypeslib.as_array(p, shape=(self.config.vocab_size,)).copy()
 
+    def get_config(self):
+        """Transformer::get_config (models/mod.rs:17)"""
+        return self.config
+
     def tap_x(self) -> np.ndarray:
         return np.ctypeslib.as_array(lib().q3o_tap_x(self._h), shape=(self.config.dim,)).copy()
 

@@ -1,0 +1,66 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "qwen3-rs_amd"))
+sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The C oracle (test infrastructure).  Built on demand with gcc."""
+    from oracle import q3_oracle
+    q3_oracle.build()
+    q3_oracle.lib()
+    return q3_oracle
+
+
+@pytest.fixture(scope="session")
+def np_oracle():
+    from oracle import np_oracle as m
+    return m
+
+
+@pytest.fixture(scope="session")
+def q3():
+    """The product package; loading the HIP library must work even on a CPU-only box (no compute calls)."""
+    import qwen3_rs_amd
+    lib = qwen3_rs_amd.lib_path()
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "qwen3-rs_amd")])
+    qwen3_rs_amd.load_library()
+    return qwen3_rs_amd
+
+
+@pytest.fixture(scope="session")
+def tmp_ckpt_dir(tmp_path_factory):
+    return str(tmp_path_factory.mktemp("q3ckpt"))
+
+
+def golden_path(name):
+    return os.path.join(GOLDEN, name)
+
+
+def bits(a):
+    import numpy as np
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.int32)
+
+
+def assert_biteq(a, b, what=""):
+    import numpy as np
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if not np.array_equal(a.view(np.int32), b.view(np.int32)):
+        bad = np.nonzero(a.view(np.int32) != b.view(np.int32))[0]
+        raise AssertionError(f"{what}: {bad.size}/{a.size} elements differ bitwise, first at {bad[0]}: "
+                             f"{a.reshape(-1)[bad[0]]!r} vs {b.reshape(-1)[bad[0]]!r}")
