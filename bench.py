@@ -186,8 +186,8 @@ def main():
                 "bytes_per_launch": int(gemv_bytes / gemv_launches),
                 "avg_launch_us": round(gemv_ms / gemv_launches * 1e3, 3),
                 "launches_per_token": gemv_launches // reps, "per_kernel": per_kernel,
-                "note": "launch period = HIP events around each eager launch on the engine stream (includes the "
-                        "~1.6 us kernel boundary); traffic: see profiles/ for the PMC pass"}
+                "note": "avg launch period = HIP events bracketing each kernel family's launches of one forward on the engine "
+                        "stream (kernel + ~1.6 us boundary, the quantity rocprofv3 per-dispatch durations sum to)"}
 
     out = {"metric": "decode tokens/sec Qwen3-0.6B Q8 g=64 @1 GPU; % of int8 HBM roofline" if args.shape == "qwen3-0.6b"
            else f"decode tokens/sec {args.shape} Q8 g=64",

@@ -233,7 +233,9 @@ GemvShape plan_gemv(int units, int n, int G, bool swiglu, int row_align, int n_c
         if (row_align % hu) continue;
         const long nb = (units + hu - 1) / hu;
         const long per_wave = (nb + waves - 1) / waves;
-        const long cost = per_wave * ru * 1000 + (ru_max - ru);   // prefer fewer sequential rows, then bigger tiles
+        // latency-bound launches (<= 2 batches per wave): fewest sequential rows per wave wins;
+        // streaming launches: the largest tile (most bytes in flight per wave) wins.
+        const long cost = per_wave <= 2 ? per_wave * ru * 1000 + (ru_max - ru) : 1000000 + (ru_max - ru);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_ru = ru; }
     }
     g.RU = best_ru;
@@ -499,6 +501,7 @@ int q3_engine::build_plan() {
             a.strict = strict;
             a.write_q = 0;
             a.debug = env_int("Q3_ABLATE", 0);
+            a.stamps = d_stamps ? d_stamps + 8 * plan.size() : nullptr;
             Ln.aa = a;
             Ln.grid = (unsigned)cfg.n_heads;
             Ln.smem = attn_smem_bytes(hd, d_att ? 0 : S);
@@ -730,12 +733,15 @@ int q3_generate_greedy(q3_engine* e, size_t first_token, size_t first_pos, size_
         HIP_TRY(hipMemcpy(h.data(), e->d_stamps, 8 * 8 * nl, hipMemcpyDeviceToHost));
         double acc[F_COUNT][8] = {}; int cnt[F_COUNT] = {};
         for (size_t i = 0; i < nl; ++i) {
-            if (e->plan[i].is_attn || e->plan[i].is_next || h[8 * i] == 0) continue;
-            for (int k = 1; k < 6; ++k) acc[e->plan[i].fam][k] += (double)(h[8 * i + k] - h[8 * i]);
+            if (e->plan[i].is_next || h[8 * i] == 0) continue;
+            for (int k = 1; k < 7; ++k) acc[e->plan[i].fam][k] += (double)(h[8 * i + k] - h[8 * i]);
+            if (!e->plan[i].is_attn && h[8 * i + 7] > h[8 * i + 6]) acc[e->plan[i].fam][7] += (double)(h[8 * i + 7] - h[8 * i + 6]);
             cnt[e->plan[i].fam]++;
         }
         for (int f = 0; f < F_COUNT; ++f)
             if (cnt[f]) fprintf(stderr, "[q3 stamps] %-8s n=%d  issue %.0f  prologue %.0f  tile %.0f  finish %.0f  end %.0f  (s_memtime ticks after entry)\n", kFamilyNames[f], cnt[f], acc[f][1] / cnt[f], acc[f][2] / cnt[f], acc[f][3] / cnt[f], acc[f][4] / cnt[f], acc[f][5] / cnt[f]);
+        for (int f = 0; f < F_COUNT; ++f) if (cnt[f] && acc[f][7] > 0) fprintf(stderr, "[q3 stamps] %-8s exact-sum %.0f ticks\n", kFamilyNames[f], acc[f][7] / cnt[f]);
+        if (cnt[F_ATTN]) fprintf(stderr, "[q3 stamps] attn: issued %.0f  norm %.0f  staged %.0f  scores %.0f  softmax %.0f  vsum %.0f\n", acc[F_ATTN][1] / cnt[F_ATTN], acc[F_ATTN][2] / cnt[F_ATTN], acc[F_ATTN][3] / cnt[F_ATTN], acc[F_ATTN][4] / cnt[F_ATTN], acc[F_ATTN][5] / cnt[F_ATTN], acc[F_ATTN][6] / cnt[F_ATTN]);
     }
     if (getenv("Q3_DEBUG_TIMING"))
         fprintf(stderr, "[q3] generate_greedy n=%zu enqueue %.1f us, drain %.1f us\n", n_tokens,
@@ -779,22 +785,26 @@ int q3_profile(q3_engine* e, size_t token, size_t pos, int reps, float* ms, int3
     HIP_TRY(hipSetDevice(e->device));
     for (int i = 0; i < cap; ++i) { ms[i] = 0.f; launches[i] = 0; }
     const size_t nl = e->plan.size();
-    std::vector<hipEvent_t> ev(nl + 1);
+    std::vector<hipEvent_t> ev(2 * F_COUNT);
     for (auto& x : ev) HIP_TRY(hipEventCreate(&x));
     for (int r = 0; r < reps; ++r) {
         int rc = e->set_state(token, pos);
         if (rc) return rc;
-        HIP_TRY(hipEventRecord(ev[0], e->stream));
-        for (size_t i = 0; i < nl; ++i) {
-            launch_one(e->plan[i], e);
-            HIP_TRY(hipEventRecord(ev[i + 1], e->stream));
+        // one full forward first so every family runs on live data, then each family's launches back to back
+        // between ONE pair of events: the average is the launch period (kernel + boundary), the same quantity
+        // rocprofv3's per-dispatch durations sum to on a serialised stream.
+        for (size_t i = 0; i < nl; ++i) if (!e->plan[i].is_next) launch_one(e->plan[i], e);
+        for (int f = 0; f < F_COUNT; ++f) {
+            HIP_TRY(hipEventRecord(ev[2 * f], e->stream));
+            for (size_t i = 0; i < nl; ++i)
+                if (e->plan[i].fam == f) { launch_one(e->plan[i], e); launches[f] += 1; }
+            HIP_TRY(hipEventRecord(ev[2 * f + 1], e->stream));
         }
         HIP_TRY(hipStreamSynchronize(e->stream));
-        for (size_t i = 0; i < nl; ++i) {
+        for (int f = 0; f < F_COUNT; ++f) {
             float t = 0.f;
-            HIP_TRY(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
-            ms[e->plan[i].fam] += t;
-            launches[e->plan[i].fam] += 1;
+            HIP_TRY(hipEventElapsedTime(&t, ev[2 * f], ev[2 * f + 1]));
+            ms[f] += t;
         }
     }
     for (auto& x : ev) (void)hipEventDestroy(x);
@@ -991,6 +1001,7 @@ int q3_op_attention(float* xb, float* q, float* key_cache_layer, const float* va
     a.seq_len = (int)seq_len;
     a.strict = (flags & Q3_FLAG_FAST) ? 0 : 1;
     a.write_q = 1;
+    a.stamps = nullptr;
     const size_t smem = attn_smem_bytes((int)head_dim, att_global ? 0 : (int)seq_len);
     if ((rc = set_max_smem((const void*)k_attn, smem))) return rc;
     hipLaunchKernelGGL(k_attn, dim3((unsigned)n_heads), dim3(kWG), smem, 0, a);

@@ -276,14 +276,35 @@ __device__ __forceinline__ float chain4(float s, v4f v) {
     s = s + v.x; s = s + v.y; s = s + v.z; s = s + v.w;
     return s;
 }
-// nq = number of float4 in the run (>= 1); p 16-byte aligned
+// nq = number of float4 in the run; p 16-byte aligned.  With one wave per SIMD nothing hides LDS latency, so
+// operands are pulled into registers a block at a time (two blocks in flight) before the dependent adds run.
 __device__ __forceinline__ float seq_chain(float s, const v4f* p, int nq) {
     int q = 0;
-    for (; q + 8 <= nq; q += 8) {
+    if (nq >= 16) {
+        v4f a[16], b[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = p[k];
+        for (; q + 32 <= nq; q += 32) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) b[k] = p[q + 16 + k];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s = chain4(s, a[k]);
+            if (q + 48 <= nq) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) a[k] = p[q + 32 + k];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s = chain4(s, b[k]);
+        }
+        if (q + 16 <= nq) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s = chain4(s, a[k]);
+            q += 16;
+        }
+    }
+    for (; q + 4 <= nq; q += 4) {
         const v4f a0 = p[q], a1 = p[q + 1], a2 = p[q + 2], a3 = p[q + 3];
-        const v4f a4 = p[q + 4], a5 = p[q + 5], a6 = p[q + 6], a7 = p[q + 7];
         s = chain4(s, a0); s = chain4(s, a1); s = chain4(s, a2); s = chain4(s, a3);
-        s = chain4(s, a4); s = chain4(s, a5); s = chain4(s, a6); s = chain4(s, a7);
     }
     for (; q < nq; ++q) s = chain4(s, p[q]);
     return s;
@@ -297,7 +318,7 @@ __device__ __forceinline__ int term_index(int i, int n) {
 }
 
 // every lane returns the exact sequential sum of the n terms stored (term_index layout) at t
-__device__ __forceinline__ float seq_sum_terms(const float* t, int n) {
+__device__ __forceinline__ float seq_sum_terms(const float* t, int n, const float* approx_tot = nullptr) {
     if (!spec_ok(n)) {
         if ((n & 3) == 0) return seq_chain(-0.0f, (const v4f*)t, n >> 2);
         float s = -0.0f;
@@ -307,29 +328,41 @@ __device__ __forceinline__ float seq_sum_terms(const float* t, int n) {
     const int blen = n / kSpecBlocks, nq = blen >> 2;
     const int j = threadIdx.x & (kSpecBlocks - 1);      // the 4 DPP rows of a wave work redundantly
     const v4f* blk = (const v4f*)(t + j * (blen + kSpecPad));
-    // approximate block totals (4 independent partial sums: order is irrelevant for a guess)
-    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-    for (int q = 0; q < nq; ++q) {
-        const v4f v = blk[q];
-        p0 += v.x; p1 += v.y; p2 += v.z; p3 += v.w;
+    // approximate block totals: only a guess, any summation order will do
+    float tot;
+    if (approx_tot != nullptr) {
+        tot = approx_tot[j];
+    } else {
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+        for (int q = 0; q < nq; ++q) {
+            const v4f v = blk[q];
+            p0 += v.x; p1 += v.y; p2 += v.z; p3 += v.w;
+        }
+        tot = (p0 + p1) + (p2 + p3);
     }
-    const float tot = (p0 + p1) + (p2 + p3);
-    // guesses g_j = running sum before block j (serial over the 16 lanes of the row, DPP row_shr:1)
-    float g = -0.0f;
-#pragma unroll
-    for (int k = 1; k < kSpecBlocks; ++k) {
-        const float pg = dpp_f<0x111>(g), pt = dpp_f<0x111>(tot);
-        if (j == k) g = pg + pt;
-    }
+    // guesses g_j = running sum before block j: exclusive prefix of the approximate totals (4-step DPP scan;
+    // a guess needs no particular order).  bound_ctrl makes out-of-row sources read 0.
+    float inc = tot;
+    inc += dpp_f<0x111>(inc);     // row_shr:1
+    inc += dpp_f<0x112>(inc);     // row_shr:2
+    inc += dpp_f<0x114>(inc);     // row_shr:4
+    inc += dpp_f<0x118>(inc);     // row_shr:8
+    float g = dpp_f<0x111>(inc);
+    if (j == 0) g = -0.0f;
     float out = seq_chain(g, blk, nq);
     for (int round = 0; round < kSpecBlocks + 1; ++round) {
-        // corrected inputs under the translation assumption: s_j = out_{j-1} + (s_{j-1} - g_{j-1})
-        float sc = -0.0f;
-#pragma unroll
-        for (int k = 1; k < kSpecBlocks; ++k) {
-            const float ps = dpp_f<0x111>(sc), po = dpp_f<0x111>(out), pg = dpp_f<0x111>(g);
-            if (j == k) sc = po + (ps - pg);
-        }
+        // corrected inputs under the translation assumption.  With e_j = out_{j-1} - g_j (the mismatch at link j)
+        // the recurrence s_j = out_{j-1} + (s_{j-1} - g_{j-1}) unrolls to s_j = g_j + sum_{i<=j} e_i: another scan.
+        // (Float adds of these few-ulp corrections are normally exact; when they are not, or a tie / binade
+        // crossing breaks the translation, the bitwise verification below fails and the loop simply repeats.)
+        float e = dpp_f<0x111>(out) - g;
+        if (j == 0) e = 0.0f;
+        e += dpp_f<0x111>(e);
+        e += dpp_f<0x112>(e);
+        e += dpp_f<0x114>(e);
+        e += dpp_f<0x118>(e);
+        float sc = g + e;
+        if (j == 0) sc = -0.0f;
         const float out2 = seq_chain(sc, blk, nq);
         // verify every link bitwise: input of block j must equal the output of block j-1
         const float prev = dpp_f<0x111>(out2);
@@ -366,6 +399,13 @@ __device__ __forceinline__ void quantize4_to_lds(v4f y, int v_idx, int glanes, b
 // (n <= 12288 floats from L2) so that no extra kernel boundary sits between the producer of the
 // activation and the weight stream that consumes it.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stamp(const GemvArgs& a, int idx) {
+    if (a.stamps != nullptr && (int)blockIdx.x == a.stamp_block && threadIdx.x == 0) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        a.stamps[idx] = t;
+    }
+}
+
 // The activation (and RMSNorm weight) loads are ISSUED before the first weight tile and CONSUMED after it
 // is in flight: vmcnt retires in order, so the prologue can run at vmcnt(#tile loads) under the weight
 // stream.  Up to kProSlots float4 slots per thread are prefetched (n <= 4096); longer vectors load the
@@ -467,6 +507,8 @@ __device__ __forceinline__ void gemv_prologue_finish(const GemvArgs& a, const Ge
     }
     // PRO_NORM / PRO_EMBED_NORM: x -> RMSNorm (layers.rs:109-119) -> quantize (tensor.rs:91-119)
     float part = 0.0f;
+    const int lanes_per_block = (n / kSpecBlocks) >> 2;     // float4 slots per speculative block
+    const bool have_approx = spec_ok(n) && lanes_per_block <= 64 && nk <= kProSlots && (nv % kWG) == 0;
 #pragma unroll
     for (int k = 0; k < kProSlots; ++k) {
         const int v = k * kWG + tid;
@@ -476,7 +518,13 @@ __device__ __forceinline__ void gemv_prologue_finish(const GemvArgs& a, const Ge
             v4f sq;
             sq.x = xv.x * xv.x; sq.y = xv.y * xv.y; sq.z = xv.z * xv.z; sq.w = xv.w * xv.w;
             *(v4f*)(sm.xf + term_index(4 * v, n)) = sq;      // squares, layers.rs:113
-            part = part + sumsq4(xv);
+            const float p4 = sumsq4(xv);
+            part = part + p4;
+            if (a.strict && have_approx) {
+                // block = blen elements = blen/4 consecutive float4 slots = consecutive threads of this slot
+                const float bt = group_sum_f32(p4, lanes_per_block);
+                if ((v & (lanes_per_block - 1)) == 0) sm.red[16 + v / lanes_per_block] = bt;
+            }
         }
     }
     for (int k = kProSlots; k < nk; ++k) {
@@ -492,8 +540,10 @@ __device__ __forceinline__ void gemv_prologue_finish(const GemvArgs& a, const Ge
     }
     float ss;
     if (a.strict) {
+        stamp(a, 6);
         __syncthreads();
-        ss = seq_sum_terms(sm.xf, n);
+        ss = seq_sum_terms(sm.xf, n, have_approx ? sm.red + 16 : nullptr);
+        stamp(a, 7);
     } else {
         ss = block_sum_fast(part, sm.red);
     }
@@ -557,29 +607,10 @@ struct RowSrc {
 
 // ascending-group sum of one row's terms (Iterator::sum from -0.0 == start at term 0)
 __device__ __forceinline__ float ordered_row_sum(const float* t, int ng) {
-    if ((ng & 3) == 0) {
-        const v4f* tv = (const v4f*)t;
-        v4f v = tv[0];
-        float acc = v.x;
-        acc = acc + v.y; acc = acc + v.z; acc = acc + v.w;
-        const int nq = ng >> 2;
-#pragma unroll 4
-        for (int q = 1; q < nq; ++q) {
-            v = tv[q];
-            acc = acc + v.x; acc = acc + v.y; acc = acc + v.z; acc = acc + v.w;
-        }
-        return acc;
-    }
+    if ((ng & 3) == 0) return seq_chain(-0.0f, (const v4f*)t, ng >> 2);
     float acc = t[0];
     for (int g = 1; g < ng; ++g) acc = acc + t[g];
     return acc;
-}
-
-__device__ __forceinline__ void stamp(const GemvArgs& a, int idx) {
-    if (a.stamps != nullptr && (int)blockIdx.x == a.stamp_block && threadIdx.x == 0) {
-        const unsigned long long t = __builtin_amdgcn_s_memtime();
-        a.stamps[idx] = t;
-    }
 }
 
 template <int PRO, int EPI, int LPG_T, int RU, int JU>
@@ -805,6 +836,7 @@ struct AttnArgs {
     int strict;
     int write_q;              // also write the normalised q back (operator-level parity)
     int debug;                // ablation: 8 = return right after the q/k norm+rope
+    unsigned long long* stamps;   // developer timeline (block 0, thread 0)
 };
 
 // LDS plan of k_attn (floats): q_s[hd] k_s[hd] raw[2hd] sq[2hd] opart[kWaves*hd] red[64] att[att_lds]
@@ -850,31 +882,35 @@ __device__ __forceinline__ void wave_norm_rope(float* dst, const float* src, flo
 constexpr int kStageSlots = 16;
 struct StageRegs { v4f v[kStageSlots]; };
 __device__ __forceinline__ void stage_issue(StageRegs& sr, const float* gbase, size_t kvd, int t0, int cnt, int hd) {
-    const int q4 = hd >> 2;                 // float4 per row
-    const int total = cnt * q4;
+    const int q4s = __builtin_ctz(hd >> 2);            // hd is a power of two: float4 per row = 1 << q4s
+    const int total = cnt << q4s;
 #pragma unroll
     for (int u = 0; u < kStageSlots; ++u) {
-        const int idx = min((int)threadIdx.x + u * kWG, total - 1);   // tail slots re-read the last float4
-        const int r = idx / q4, c = idx - r * q4;
-        sr.v[u] = *(const v4f*)(gbase + (size_t)(t0 + r) * kvd + 4 * c);
+        if (u * kWG < total) {                          // wave-uniform: short contexts issue only the slots they need
+            const int idx = min((int)threadIdx.x + u * kWG, total - 1);
+            const int r = idx >> q4s, c = idx & ((1 << q4s) - 1);
+            sr.v[u] = *(const v4f*)(gbase + (size_t)(t0 + r) * kvd + 4 * c);
+        }
     }
 }
 // rows land at lds + r*ld; `skip` (absolute timestep or -1) is left untouched
 __device__ __forceinline__ void stage_commit(const StageRegs& sr, float* lds, int ld, int t0, int cnt, int hd, int skip) {
-    const int q4 = hd >> 2;
-    const int total = cnt * q4;
+    const int q4s = __builtin_ctz(hd >> 2);
+    const int total = cnt << q4s;
 #pragma unroll
     for (int u = 0; u < kStageSlots; ++u) {
         const int idx = (int)threadIdx.x + u * kWG;
         if (idx < total) {
-            const int r = idx / q4, c = idx - r * q4;
+            const int r = idx >> q4s, c = idx & ((1 << q4s) - 1);
             if (t0 + r != skip) *(v4f*)(lds + r * ld + 4 * c) = sr.v[u];
         }
     }
 }
 
+#define ATT_STAMP(i) do { if (a.stamps != nullptr && blockIdx.x == 3 && threadIdx.x == 0) a.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 __global__ __launch_bounds__(kWG) void k_attn(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    ATT_STAMP(0);
     const int hd = a.hd;
     const int tch = attn_tch(hd);
     const int kld = hd + kKPad;
@@ -914,6 +950,7 @@ __global__ __launch_bounds__(kWG) void k_attn(const AttnArgs a) {
     stage_issue(sk, kbase, kvd, 0, cnt0, hd);
     stage_issue(sv, vbase, kvd, 0, cnt0, hd);
     __builtin_amdgcn_sched_barrier(0);
+    ATT_STAMP(1);
     if (tid < hd) {
         raw[tid] = rq;
         raw[hd + tid] = rk;
@@ -922,9 +959,11 @@ __global__ __launch_bounds__(kWG) void k_attn(const AttnArgs a) {
     // ---- waves 0/1: QK-RMSNorm + RoPE of q / k (layers.rs:346-372) under the K/V loads
     if (wave == 0) wave_norm_rope(q_s, raw, sq, a.q_norm_w, cs, hd, a.strict);
     else if (wave == 1) wave_norm_rope(k_s, raw + hd, sq + hd, a.k_norm_w, cs, hd, a.strict);
+    ATT_STAMP(2);
     stage_commit(sk, kbuf, kld, 0, cnt0, hd, pos);
     stage_commit(sv, vbuf, hd, 0, cnt0, hd, -1);
     __syncthreads();
+    ATT_STAMP(3);
     float* krow = a.key_cache + (size_t)pos * kvd + (size_t)kvh * hd;
     if (h % kv_mul == 0)
         for (int i = tid; i < hd; i += kWG) krow[i] = k_s[i];   // K is normalised + rotated in place in the cache
@@ -947,12 +986,25 @@ __global__ __launch_bounds__(kWG) void k_attn(const AttnArgs a) {
         __syncthreads();
         if (a.strict) {
             for (int t = tid; t < cnt; t += kWG) {
-                const float* k = kbuf + t * kld;
+                const v4f* k4 = (const v4f*)(kbuf + t * kld);
+                const v4f* q4 = (const v4f*)q_s;
                 float dot = -0.0f;
-#pragma unroll 4
-                for (int i = 0; i < hd; i += 4) {
-                    const v4f kv = *(const v4f*)(k + i);
-                    const v4f qv = *(const v4f*)(q_s + i);
+                const int nq = hd >> 2;
+                int i = 0;
+                for (; i + 16 <= nq; i += 16) {          // operands first, then the sequential dot (layers.rs:395-400)
+                    v4f kk[16], qq[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) { kk[u] = k4[i + u]; qq[u] = q4[i + u]; }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        float p = qq[u].x * kk[u].x; dot = dot + p;
+                        p = qq[u].y * kk[u].y; dot = dot + p;
+                        p = qq[u].z * kk[u].z; dot = dot + p;
+                        p = qq[u].w * kk[u].w; dot = dot + p;
+                    }
+                }
+                for (; i < nq; ++i) {
+                    const v4f kv = k4[i], qv = q4[i];
                     float p = qv.x * kv.x; dot = dot + p;
                     p = qv.y * kv.y; dot = dot + p;
                     p = qv.z * kv.z; dot = dot + p;
@@ -981,6 +1033,7 @@ __global__ __launch_bounds__(kWG) void k_attn(const AttnArgs a) {
         }
     }
     __syncthreads();
+    ATT_STAMP(4);
 
     // ---- softmax                                                              layers.rs:495-506
     float m = -__builtin_inff();
@@ -1006,6 +1059,7 @@ __global__ __launch_bounds__(kWG) void k_attn(const AttnArgs a) {
     for (int t = tid; t < np; t += kWG) att[t] = att[t] * inv;
     __syncthreads();
 
+    ATT_STAMP(5);
     // ---- xb = sum_t att[t] * V[t]                                              layers.rs:406-417
     float* out = a.xb + (size_t)h * hd;
     float o_s = 0.0f;                       // strict: element tid (fill(0.0) then += in t order)
@@ -1025,12 +1079,12 @@ __global__ __launch_bounds__(kWG) void k_attn(const AttnArgs a) {
                 const float* v = vbuf + tid;
                 const float* w = att + t0;
                 int t = 0;
-                for (; t + 8 <= cnt; t += 8) {
-                    float vv[8], ww[8];
+                for (; t + 16 <= cnt; t += 16) {
+                    float vv[16], ww[16];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { vv[u] = v[(t + u) * hd]; ww[u] = w[t + u]; }
+                    for (int u = 0; u < 16; ++u) { vv[u] = v[(t + u) * hd]; ww[u] = w[t + u]; }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { const float p = ww[u] * vv[u]; o_s = o_s + p; }
+                    for (int u = 0; u < 16; ++u) { const float p = ww[u] * vv[u]; o_s = o_s + p; }
                 }
                 for (; t < cnt; ++t) { const float p = w[t] * v[t * hd]; o_s = o_s + p; }
             }
@@ -1048,6 +1102,7 @@ __global__ __launch_bounds__(kWG) void k_attn(const AttnArgs a) {
             }
         }
     }
+    ATT_STAMP(6);
     if (a.strict) {
         if (tid < hd) out[tid] = o_s;
     } else {
