@@ -687,8 +687,13 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
 #pragma unroll
             for (int j = 0; j < JU; ++j) {
                 const int c = min(lane + 64 * (jt * JU + j), nchunks - 1);   // tail chunks clamp
-                T.w[r][j] = __builtin_nontemporal_load((const v4i*)wrow + c);
-                T.sc[r][j] = __builtin_nontemporal_load(srow + (c >> lpg_shift));
+                if (a.debug & 16) {      // experiment: plain (L2-allocating) loads
+                    T.w[r][j] = *((const v4i*)wrow + c);
+                    T.sc[r][j] = *(srow + (c >> lpg_shift));
+                } else {
+                    T.w[r][j] = __builtin_nontemporal_load((const v4i*)wrow + c);
+                    T.sc[r][j] = __builtin_nontemporal_load(srow + (c >> lpg_shift));
+                }
             }
         }
     };
@@ -850,9 +855,23 @@ __host__ __device__ inline size_t attn_smem_bytes(int hd, int att_lds_floats) {
     return 4 * ((size_t)hd * (6 + kWaves) + 64 + (size_t)((att_lds_floats + 3) & ~3) + (size_t)tch * (2 * hd + kKPad));
 }
 
+// per-lane operands of the norm+RoPE of one head: lane l owns rotation pairs (l, l+64, ...) -> at most 2 pairs
+// for hd <= 256.  Loaded at kernel entry so their global latency overlaps everything else.
+struct RopeRegs { float w_lo[2], w_hi[2], c[2], s[2]; };
+__device__ __forceinline__ void rope_regs_load(RopeRegs& r, const float* w, const float* cs, int hd) {
+    const int lane = threadIdx.x & 63, half = hd >> 1;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = min(lane + 64 * u, half - 1);
+        r.w_lo[u] = w[i];
+        r.w_hi[u] = w[i + half];
+        r.c[u] = cs[2 * i];
+        r.s[u] = cs[2 * i + 1];
+    }
+}
 // one WAVE: RMSNorm over hd raw values (LDS) followed by RoPE -> dst (LDS).  layers.rs:109-119,173-185
-__device__ __forceinline__ void wave_norm_rope(float* dst, const float* src, float* sq, const float* w, const float* cs,
-                                               int hd, int strict) {
+__device__ __forceinline__ void wave_norm_rope(float* dst, const float* src, float* sq, const RopeRegs& rr, int hd,
+                                               int strict) {
     const int lane = threadIdx.x & 63;
     float ss;
     if (strict) {
@@ -866,14 +885,17 @@ __device__ __forceinline__ void wave_norm_rope(float* dst, const float* src, flo
     }
     const float f = 1.0f / sqrtf(ss / (float)hd + kEps);
     const int half = hd >> 1;
-    for (int i = lane; i < half; i += 64) {
-        const float xv = w[i] * (f * src[i]);
-        const float yv = w[i + half] * (f * src[i + half]);
-        const float c = cs[2 * i], sn = cs[2 * i + 1];
-        const float a0 = xv * c, b0 = yv * sn;
-        const float a1 = xv * sn, b1 = yv * c;
-        dst[i] = a0 - b0;            // layers.rs:181-182
-        dst[i + half] = a1 + b1;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = lane + 64 * u;
+        if (i < half) {
+            const float xv = rr.w_lo[u] * (f * src[i]);
+            const float yv = rr.w_hi[u] * (f * src[i + half]);
+            const float a0 = xv * rr.c[u], b0 = yv * rr.s[u];
+            const float a1 = xv * rr.s[u], b1 = yv * rr.c[u];
+            dst[i] = a0 - b0;            // layers.rs:181-182
+            dst[i + half] = a1 + b1;
+        }
     }
 }
 
@@ -946,6 +968,8 @@ __global__ __launch_bounds__(kWG) void k_attn(const AttnArgs a) {
     }
     const int cnt0 = min(tch, np);
     StageRegs sk, sv;
+    RopeRegs rr;
+    rope_regs_load(rr, wave == 0 ? a.q_norm_w : a.k_norm_w, cs, hd);
     __builtin_amdgcn_sched_barrier(0);
     stage_issue(sk, kbase, kvd, 0, cnt0, hd);
     stage_issue(sv, vbase, kvd, 0, cnt0, hd);
@@ -957,8 +981,8 @@ __global__ __launch_bounds__(kWG) void k_attn(const AttnArgs a) {
     }
     __syncthreads();
     // ---- waves 0/1: QK-RMSNorm + RoPE of q / k (layers.rs:346-372) under the K/V loads
-    if (wave == 0) wave_norm_rope(q_s, raw, sq, a.q_norm_w, cs, hd, a.strict);
-    else if (wave == 1) wave_norm_rope(k_s, raw + hd, sq + hd, a.k_norm_w, cs, hd, a.strict);
+    if (wave == 0) wave_norm_rope(q_s, raw, sq, rr, hd, a.strict);
+    else if (wave == 1) wave_norm_rope(k_s, raw + hd, sq + hd, rr, hd, a.strict);
     ATT_STAMP(2);
     stage_commit(sk, kbuf, kld, 0, cnt0, hd, pos);
     stage_commit(sv, vbuf, hd, 0, cnt0, hd, -1);

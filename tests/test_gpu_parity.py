@@ -193,6 +193,36 @@ def test_forward_vs_oracle_live(q3, oracle, tmp_ckpt_dir, name, ctx):
             assert np.max(np.abs(a - b)) <= 2e-5, np.max(np.abs(a - b))
 
 
+@pytest.mark.parametrize("name", ["qwen3-4b-dims-l2", "qwen3-8b-dims-l2"])
+def test_big_layer_dims_vs_oracle(q3, oracle, name):
+    """BASELINE configs 3-5 use the 4B / 8B layer shapes: row lengths 2560 / 9728 (not multiples of 1 KiB),
+    4096 / 12288 (several tiles per row), 32 heads over 8 kv heads, untied classifier.  2-layer, reduced-vocab
+    variants keep the oracle in seconds; the chat-mode pattern (every prompt token forwarded, generation.rs:116-123)
+    is used so that prefill positions are covered."""
+    ck = q3.checkpoint
+    path = os.path.join(os.environ.get("Q3_CKPT_DIR", "/tmp"), f"q3_{name}.bin")
+    ck.ensure_synthetic_checkpoint(path, ck.SHAPES[name], seed=1235)
+    om = oracle.OracleModel(path, 256)
+    with q3.TransformerBuilder(path).with_ctx_length(256).build() as t:
+        prompt = ck.iter_prompt_tokens(ck.SHAPES[name], 1235, 5)
+        seen, last = [], {}
+
+        def check(tok, pos, logits):
+            assert_biteq(logits, om.forward(tok, pos), f"{name} forward({tok},{pos})")
+            seen.append(pos)
+            last["logits"] = logits
+
+        toks, pos, _ = q3.chat_turn(t, prompt, 0, 4, on_logits=check)
+        assert seen == list(range(9)) and pos == 9 and len(toks) == 4
+        # the device-resident loop continues the same sequence: 3 more tokens, compared with the oracle
+        tok = oracle.sample_argmax(last["logits"])
+        want, ot = [], tok
+        for p in range(9, 12):
+            ot = oracle.sample_argmax(om.forward(ot, p))
+            want.append(ot)
+        assert t.generate_greedy(tok, 9, 3) == want
+
+
 def test_engine_error_behaviour(q3, tmp_ckpt_dir):
     """Same failure surface as TransformerBuilder::build / forward in the reference."""
     with pytest.raises(q3.Q3Error, match="Failed to open checkpoint"):
