@@ -230,7 +230,7 @@ GemvShape plan_gemv(int units, int n, int G, bool swiglu, int row_align, int n_c
     for (int ru = ru_max; ru >= ru_min; ru >>= 1) {
         if (G != 64 && ru != ru_min) continue;
         const int hu = swiglu ? ru / 2 : ru;
-        if (row_align % hu) continue;
+        if (row_align > 1 && row_align % hu) continue;   // QKV: batches must not straddle q|k|v segments
         const long nb = (units + hu - 1) / hu;
         const long per_wave = (nb + waves - 1) / waves;
         // latency-bound launches (<= 2 batches per wave): fewest sequential rows per wave wins;
@@ -913,7 +913,7 @@ int q3_op_rmsnorm(float* out, const float* in, const float* weight, size_t n, ui
     if (n == 0 || n > 32768) return fail(Q3_ERR_UNSUPPORTED, "unsupported n");
     DevBuf di, dw, dout;
     if ((rc = di.upload(in, 4 * n)) || (rc = dw.upload(weight, 4 * n)) || (rc = dout.alloc(4 * n))) return rc;
-    const size_t smem = 4 * (size_t)term_floats((int)n) + 256;
+    const size_t smem = 4 * (size_t)term_floats((int)n) + 512;
     if ((rc = set_max_smem((const void*)k_op_rmsnorm, smem))) return rc;
     hipLaunchKernelGGL(k_op_rmsnorm, dim3(1), dim3(kWG), smem, 0, dout.as<float>(), di.as<float>(), dw.as<float>(), (int)n,
                        (flags & Q3_FLAG_FAST) ? 0 : 1);

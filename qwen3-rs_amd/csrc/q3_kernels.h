@@ -203,11 +203,12 @@ struct GemvArgs {
 //   [n16, +4*n/G)             xs   f32    activation group scales
 //   [.., +4*n)                xf   f32    staged activation (PRO_NORM only)
 //   [.., +4*kWaves*vr*NG)     term f32    per-wave group terms
-//   [.., +64*4)               red  f32    block reduction scratch
-constexpr int kSpecBlocks = 16;   // one DPP row
-constexpr int kSpecPad = 4;       // floats of padding per block: lane j's b128 reads hit distinct banks
-__host__ __device__ inline bool spec_ok(int n) { return n >= 512 && (n % (kSpecBlocks * 32)) == 0; }
-__host__ __device__ inline int term_floats(int n) { return n + kSpecBlocks * kSpecPad; }
+//   [.., +128*4)              red  f32    block reduction scratch + approximate block totals
+// Exact speculative sum geometry: blocks of kSpecBlen terms, one lane per block, up to 64 blocks (n <= 4096).
+constexpr int kSpecBlen = 64;
+constexpr int kSpecPad = 4;       // floats of padding per block: lane j's b128 reads hit distinct banks (17j mod 64)
+__host__ __device__ inline bool spec_ok(int n) { return n >= 512 && n <= 64 * kSpecBlen && (n % kSpecBlen) == 0; }
+__host__ __device__ inline int term_floats(int n) { return n + 64 * kSpecPad; }
 
 struct GemvSmem {
     int8_t* xq;
@@ -221,7 +222,7 @@ __host__ __device__ inline size_t gemv_smem_bytes(int n, int group, int vr, bool
     size_t b = align16((size_t)n) + align16(4 * (size_t)(n / group));
     if (stage_f32) b += align16(4 * (size_t)term_floats(n));
     b += align16(4 * (size_t)kWaves * vr * (n / group));
-    b += 64 * 4;
+    b += 128 * 4;
     return b;
 }
 __device__ __forceinline__ GemvSmem gemv_carve(char* base, int n, int group, int vr, bool stage_f32) {
@@ -265,41 +266,42 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // chain.  `t` holds the terms; the result is bit-identical to  (((-0.0 + t0) + t1) + ...).
 //
 // seq_chain():  one lane-uniform left fold over a contiguous run, LDS reads software-pipelined.
-// seq_sum_spec():  16 lanes fold 16 blocks concurrently from GUESSED running sums.  Adding a block of
+// seq_sum_terms():  up to 64 lanes fold 64-term blocks concurrently from GUESSED running sums.  Adding a block of
 //   small non-negative terms to a large accumulator is (barring ties / binade crossings) a translation,
 //   out(s + d) = out(s) + d, so one correction sweep turns approximate guesses into (almost always)
 //   exact block inputs; a second fold VERIFIES them bitwise (out_j == in_{j+1} for all j).  If any link
 //   fails the loop repeats: block 0's input is exact by construction and round r fixes block r, so it
-//   terminates, exact, in <= 16 rounds (2 in practice).  ~4x shorter critical path than the plain chain.
+//   terminates, exact, in <= 64 rounds (1 in practice).  Critical path: two 64-add folds, independent of n.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float chain4(float s, v4f v) {
     s = s + v.x; s = s + v.y; s = s + v.z; s = s + v.w;
     return s;
 }
-// nq = number of float4 in the run; p 16-byte aligned.  With one wave per SIMD nothing hides LDS latency, so
-// operands are pulled into registers a block at a time (two blocks in flight) before the dependent adds run.
+// nq = number of float4 in the run; p 16-byte aligned.  A dependent v_add_f32 costs 9 cycles and an LDS read ~60
+// on gfx950, and with one wave per SIMD nothing hides either: operands are pulled in 8-float4 blocks, the next
+// block in flight while the current one (32 adds = 288 cycles) is folded.  64 VGPRs, no more (occupancy).
 __device__ __forceinline__ float seq_chain(float s, const v4f* p, int nq) {
     int q = 0;
-    if (nq >= 16) {
-        v4f a[16], b[16];
+    if (nq >= 8) {
+        v4f a[8], b[8];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) a[k] = p[k];
-        for (; q + 32 <= nq; q += 32) {
+        for (int k = 0; k < 8; ++k) a[k] = p[k];
+        for (; q + 16 <= nq; q += 16) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) b[k] = p[q + 16 + k];
+            for (int k = 0; k < 8; ++k) b[k] = p[q + 8 + k];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) s = chain4(s, a[k]);
-            if (q + 48 <= nq) {
+            for (int k = 0; k < 8; ++k) s = chain4(s, a[k]);
+            if (q + 24 <= nq) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) a[k] = p[q + 32 + k];
+                for (int k = 0; k < 8; ++k) a[k] = p[q + 16 + k];
             }
 #pragma unroll
-            for (int k = 0; k < 16; ++k) s = chain4(s, b[k]);
+            for (int k = 0; k < 8; ++k) s = chain4(s, b[k]);
         }
-        if (q + 16 <= nq) {
+        if (q + 8 <= nq) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) s = chain4(s, a[k]);
-            q += 16;
+            for (int k = 0; k < 8; ++k) s = chain4(s, a[k]);
+            q += 8;
         }
     }
     for (; q + 4 <= nq; q += 4) {
@@ -313,8 +315,7 @@ __device__ __forceinline__ float seq_chain(float s, const v4f* p, int nq) {
 // LDS float index of term i in the (possibly padded) term array
 __device__ __forceinline__ int term_index(int i, int n) {
     if (!spec_ok(n)) return i;
-    const int blen = n / kSpecBlocks;
-    return (i / blen) * (blen + kSpecPad) + (i % blen);
+    return (i / kSpecBlen) * (kSpecBlen + kSpecPad) + (i % kSpecBlen);
 }
 
 // every lane returns the exact sequential sum of the n terms stored (term_index layout) at t
@@ -325,14 +326,32 @@ __device__ __forceinline__ float seq_sum_terms(const float* t, int n, const floa
         for (int i = 0; i < n; ++i) s = s + t[i];
         return s;
     }
-    const int blen = n / kSpecBlocks, nq = blen >> 2;
-    const int j = threadIdx.x & (kSpecBlocks - 1);      // the 4 DPP rows of a wave work redundantly
-    const v4f* blk = (const v4f*)(t + j * (blen + kSpecPad));
+    const int nblk = n / kSpecBlen;                     // 8..64 blocks, lane j folds block j
+    constexpr int nq = kSpecBlen >> 2;
+    const int j = threadIdx.x & 63;
+    const bool live = j < nblk;
+    const v4f* blk = (const v4f*)(t + (live ? j : 0) * (kSpecBlen + kSpecPad));
+    // inclusive scan over the wave: DPP row_shr within the 16-lane rows, then the row totals of the rows below
+    // (v_readlane).  Only used for guesses and corrections, whose exactness is verified afterwards.
+    auto wave_scan = [&](float v) {
+        v += dpp_f<0x111>(v);
+        v += dpp_f<0x112>(v);
+        v += dpp_f<0x114>(v);
+        v += dpp_f<0x118>(v);
+        const float r0 = __shfl(v, 15), r1 = __shfl(v, 31), r2 = __shfl(v, 47);
+        const int row = j >> 4;
+        if (row == 1) v += r0;
+        else if (row == 2) v += r0 + r1;
+        else if (row == 3) v += (r0 + r1) + r2;
+        return v;
+    };
+    // previous lane's value across the whole wave (row_shr:1 does not cross DPP rows)
+    auto prev_lane = [&](float v) { return __shfl_up(v, 1); };
     // approximate block totals: only a guess, any summation order will do
-    float tot;
+    float tot = 0.0f;
     if (approx_tot != nullptr) {
-        tot = approx_tot[j];
-    } else {
+        if (live) tot = approx_tot[j];
+    } else if (live) {
         float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
         for (int q = 0; q < nq; ++q) {
             const v4f v = blk[q];
@@ -340,38 +359,30 @@ __device__ __forceinline__ float seq_sum_terms(const float* t, int n, const floa
         }
         tot = (p0 + p1) + (p2 + p3);
     }
-    // guesses g_j = running sum before block j: exclusive prefix of the approximate totals (4-step DPP scan;
-    // a guess needs no particular order).  bound_ctrl makes out-of-row sources read 0.
-    float inc = tot;
-    inc += dpp_f<0x111>(inc);     // row_shr:1
-    inc += dpp_f<0x112>(inc);     // row_shr:2
-    inc += dpp_f<0x114>(inc);     // row_shr:4
-    inc += dpp_f<0x118>(inc);     // row_shr:8
-    float g = dpp_f<0x111>(inc);
+    // guesses g_j = running sum before block j: exclusive prefix of the approximate totals
+    float g = prev_lane(wave_scan(tot));
     if (j == 0) g = -0.0f;
     float out = seq_chain(g, blk, nq);
-    for (int round = 0; round < kSpecBlocks + 1; ++round) {
+    for (int round = 0; round < 65; ++round) {
         // corrected inputs under the translation assumption.  With e_j = out_{j-1} - g_j (the mismatch at link j)
         // the recurrence s_j = out_{j-1} + (s_{j-1} - g_{j-1}) unrolls to s_j = g_j + sum_{i<=j} e_i: another scan.
         // (Float adds of these few-ulp corrections are normally exact; when they are not, or a tie / binade
-        // crossing breaks the translation, the bitwise verification below fails and the loop simply repeats.)
-        float e = dpp_f<0x111>(out) - g;
-        if (j == 0) e = 0.0f;
-        e += dpp_f<0x111>(e);
-        e += dpp_f<0x112>(e);
-        e += dpp_f<0x114>(e);
-        e += dpp_f<0x118>(e);
+        // crossing breaks the translation, the bitwise verification below fails and the loop simply repeats:
+        // block 0's input is exact by construction and round r fixes block r.)
+        float e = prev_lane(out) - g;
+        if (j == 0 || !live) e = 0.0f;
+        e = wave_scan(e);
         float sc = g + e;
         if (j == 0) sc = -0.0f;
         const float out2 = seq_chain(sc, blk, nq);
         // verify every link bitwise: input of block j must equal the output of block j-1
-        const float prev = dpp_f<0x111>(out2);
-        const bool ok = (j == 0) || (__float_as_uint(prev) == __float_as_uint(sc));
+        const float prev = prev_lane(out2);
+        const bool ok = (j == 0) || !live || (__float_as_uint(prev) == __float_as_uint(sc));
         g = sc;
         out = out2;
         if (__all(ok)) break;
     }
-    return __shfl(out, kSpecBlocks - 1);   // block 15's output of lane 15 (row 0)
+    return __shfl(out, nblk - 1);   // the last block's output
 }
 
 // quantize 4 consecutive values held by this thread; its quantization group spans `glanes` = G/4
@@ -507,8 +518,8 @@ __device__ __forceinline__ void gemv_prologue_finish(const GemvArgs& a, const Ge
     }
     // PRO_NORM / PRO_EMBED_NORM: x -> RMSNorm (layers.rs:109-119) -> quantize (tensor.rs:91-119)
     float part = 0.0f;
-    const int lanes_per_block = (n / kSpecBlocks) >> 2;     // float4 slots per speculative block
-    const bool have_approx = spec_ok(n) && lanes_per_block <= 64 && nk <= kProSlots && (nv % kWG) == 0;
+    constexpr int lanes_per_block = kSpecBlen >> 2;         // 16 float4 slots (threads) per speculative block
+    const bool have_approx = spec_ok(n) && nk <= kProSlots && (nv % kWG) == 0;
 #pragma unroll
     for (int k = 0; k < kProSlots; ++k) {
         const int v = k * kWG + tid;
@@ -523,7 +534,7 @@ __device__ __forceinline__ void gemv_prologue_finish(const GemvArgs& a, const Ge
             if (a.strict && have_approx) {
                 // block = blen elements = blen/4 consecutive float4 slots = consecutive threads of this slot
                 const float bt = group_sum_f32(p4, lanes_per_block);
-                if ((v & (lanes_per_block - 1)) == 0) sm.red[16 + v / lanes_per_block] = bt;
+                if ((v & (lanes_per_block - 1)) == 0) sm.red[64 + v / lanes_per_block] = bt;
             }
         }
     }
@@ -542,7 +553,7 @@ __device__ __forceinline__ void gemv_prologue_finish(const GemvArgs& a, const Ge
     if (a.strict) {
         stamp(a, 6);
         __syncthreads();
-        ss = seq_sum_terms(sm.xf, n, have_approx ? sm.red + 16 : nullptr);
+        ss = seq_sum_terms(sm.xf, n, have_approx ? sm.red + 64 : nullptr);
         stamp(a, 7);
     } else {
         ss = block_sum_fast(part, sm.red);
@@ -605,9 +616,30 @@ struct RowSrc {
     float resid;         // EPI_RESID: x[row] of this lane's row, requested together with the batch's first tile
 };
 
-// ascending-group sum of one row's terms (Iterator::sum from -0.0 == start at term 0)
+// ascending-group sum of one row's terms (Iterator::sum from -0.0 == start at term 0).  Lean on registers
+// (4+4 float4): it runs while two weight tiles are live, and VGPRs decide the streaming kernels' occupancy.
 __device__ __forceinline__ float ordered_row_sum(const float* t, int ng) {
-    if ((ng & 3) == 0) return seq_chain(-0.0f, (const v4f*)t, ng >> 2);
+    if ((ng & 3) == 0) {
+        const v4f* p = (const v4f*)t;
+        const int nq = ng >> 2;
+        float s = -0.0f;
+        int q = 0;
+        if (nq >= 4) {
+            v4f a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+            for (; q + 8 <= nq; q += 8) {
+                const v4f b0 = p[q + 4], b1 = p[q + 5], b2 = p[q + 6], b3 = p[q + 7];
+                s = chain4(s, a0); s = chain4(s, a1); s = chain4(s, a2); s = chain4(s, a3);
+                if (q + 12 <= nq) { a0 = p[q + 8]; a1 = p[q + 9]; a2 = p[q + 10]; a3 = p[q + 11]; }
+                s = chain4(s, b0); s = chain4(s, b1); s = chain4(s, b2); s = chain4(s, b3);
+            }
+            if (q + 4 <= nq) {
+                s = chain4(s, a0); s = chain4(s, a1); s = chain4(s, a2); s = chain4(s, a3);
+                q += 4;
+            }
+        }
+        for (; q < nq; ++q) s = chain4(s, p[q]);
+        return s;
+    }
     float acc = t[0];
     for (int g = 1; g < ng; ++g) acc = acc + t[g];
     return acc;
@@ -687,13 +719,8 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
 #pragma unroll
             for (int j = 0; j < JU; ++j) {
                 const int c = min(lane + 64 * (jt * JU + j), nchunks - 1);   // tail chunks clamp
-                if (a.debug & 16) {      // experiment: plain (L2-allocating) loads
-                    T.w[r][j] = *((const v4i*)wrow + c);
-                    T.sc[r][j] = *(srow + (c >> lpg_shift));
-                } else {
-                    T.w[r][j] = __builtin_nontemporal_load((const v4i*)wrow + c);
-                    T.sc[r][j] = __builtin_nontemporal_load(srow + (c >> lpg_shift));
-                }
+                T.w[r][j] = __builtin_nontemporal_load((const v4i*)wrow + c);
+                T.sc[r][j] = __builtin_nontemporal_load(srow + (c >> lpg_shift));
             }
         }
     };
