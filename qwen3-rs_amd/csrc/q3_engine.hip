@@ -420,7 +420,7 @@ int q3_engine::build_plan() {
     const int dim = cfg.dim, L = cfg.n_layers, hd = cfg.head_dim, V = cfg.vocab_size, H = cfg.hidden_dim;
     const int G = cfg.group_size, ahd = cfg.n_heads * hd, kvd = cfg.n_kv_heads * hd, S = cfg.seq_len;
     const int strict = (flags & Q3_FLAG_FAST) ? 0 : 1;
-    const int small_cap = env_int("Q3_WG_PER_CU_SMALL", 2);
+    const int small_cap = env_int("Q3_WG_PER_CU_SMALL", 1);
     const int big_cap = env_int("Q3_WG_PER_CU_LMHEAD", 4);
     const int att_lds_max = env_int("Q3_ATT_LDS_MAX", 4096);
 

@@ -709,7 +709,25 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
         rs.resid = (EPI == EPI_RESID) ? rs.out[min(lane, rs.cnt - 1)] : 0.0f;
         return rs;
     };
+    const bool chunks_fit = (nchunks % (64 * JU)) == 0;      // every lane of every j-tile is inside the row
     auto load_tile = [&](Tile<RU, JU>& T, const RowSrc& rs, int jt) {
+        if (chunks_fit && rs.cnt == HU) {
+            // exact fit (all listed models' layer shapes): base + constant strides, no clamps
+            const int c0 = lane + 64 * JU * jt;
+#pragma unroll
+            for (int r = 0; r < RU; ++r) {
+                const int part = (EPI == EPI_SWIGLU && r >= HU) ? 1 : 0;
+                const int lr = r - part * HU;
+                const v4i* wrow = (const v4i*)(rs.w[part] + (size_t)lr * n) + c0;
+                const float* srow = rs.s[part] + (size_t)lr * ng + (c0 >> lpg_shift);
+#pragma unroll
+                for (int j = 0; j < JU; ++j) {
+                    T.w[r][j] = __builtin_nontemporal_load(wrow + 64 * j);
+                    T.sc[r][j] = __builtin_nontemporal_load(srow + ((64 * j) >> lpg_shift));
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < RU; ++r) {
             const int part = (EPI == EPI_SWIGLU && r >= HU) ? 1 : 0;
@@ -930,29 +948,32 @@ __device__ __forceinline__ void wave_norm_rope(float* dst, const float* src, flo
 // loads are issued at once (one round trip) and written to LDS later, so other work overlaps the flight.
 constexpr int kStageSlots = 16;
 struct StageRegs { v4f v[kStageSlots]; };
+// thread `tid` owns float4 column c = tid % (hd/4) of rows r0 + u*rps (u = slot): consecutive slots are a constant
+// number of rows apart, so one base address + a stride replaces per-slot index arithmetic.
 __device__ __forceinline__ void stage_issue(StageRegs& sr, const float* gbase, size_t kvd, int t0, int cnt, int hd) {
     const int q4s = __builtin_ctz(hd >> 2);            // hd is a power of two: float4 per row = 1 << q4s
-    const int total = cnt << q4s;
+    const int rps = kWG >> q4s;                         // rows covered by one slot of the whole workgroup
+    const int r0 = (int)threadIdx.x >> q4s, c = (int)threadIdx.x & ((1 << q4s) - 1);
+    const float* p = gbase + (size_t)(t0 + r0) * kvd + 4 * c;
+    const size_t stride = (size_t)rps * kvd;
 #pragma unroll
     for (int u = 0; u < kStageSlots; ++u) {
-        if (u * kWG < total) {                          // wave-uniform: short contexts issue only the slots they need
-            const int idx = min((int)threadIdx.x + u * kWG, total - 1);
-            const int r = idx >> q4s, c = idx & ((1 << q4s) - 1);
-            sr.v[u] = *(const v4f*)(gbase + (size_t)(t0 + r) * kvd + 4 * c);
+        if (u * rps < cnt) {                            // wave-uniform: short contexts issue only the slots they need
+            const bool ok = r0 + u * rps < cnt;
+            sr.v[u] = *(const v4f*)(ok ? p + u * stride : p);   // tail rows re-read a valid address
         }
     }
 }
 // rows land at lds + r*ld; `skip` (absolute timestep or -1) is left untouched
 __device__ __forceinline__ void stage_commit(const StageRegs& sr, float* lds, int ld, int t0, int cnt, int hd, int skip) {
     const int q4s = __builtin_ctz(hd >> 2);
-    const int total = cnt << q4s;
+    const int rps = kWG >> q4s;
+    const int r0 = (int)threadIdx.x >> q4s, c = (int)threadIdx.x & ((1 << q4s) - 1);
+    float* p = lds + r0 * ld + 4 * c;
 #pragma unroll
     for (int u = 0; u < kStageSlots; ++u) {
-        const int idx = (int)threadIdx.x + u * kWG;
-        if (idx < total) {
-            const int r = idx >> q4s, c = idx & ((1 << q4s) - 1);
-            if (t0 + r != skip) *(v4f*)(lds + r * ld + 4 * c) = sr.v[u];
-        }
+        const int r = r0 + u * rps;
+        if (r < cnt && t0 + r != skip) *(v4f*)(p + u * rps * ld) = sr.v[u];
     }
 }
 
