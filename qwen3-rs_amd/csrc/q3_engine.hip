@@ -221,6 +221,9 @@ void launch_one(const Launch& L, q3_engine* e) {
 struct GemvShape { int RU, JU; unsigned grid; };
 GemvShape plan_gemv(int units, int n, int G, bool swiglu, int row_align, int n_cu, int wg_per_cu) {
     GemvShape g;
+    // launches that stream >= 16 MB are bandwidth- rather than latency-bound: give them a second workgroup per CU
+    const size_t launch_bytes = (size_t)units * (swiglu ? 2 : 1) * (size_t)n;
+    if (launch_bytes >= (16u << 20) && wg_per_cu < 2) wg_per_cu = 2;
     const int nj = (n + 1023) / 1024;
     g.JU = nj == 1 ? 1 : (nj == 2 ? 2 : 4);
     const int ru_max = 8 / g.JU, ru_min = swiglu ? 2 : 1;
