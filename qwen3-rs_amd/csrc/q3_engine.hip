@@ -688,14 +688,28 @@ const float* q3_forward(q3_engine* e, size_t token, size_t pos) {
         fail(Q3_ERR_ARG, "null engine");
         return nullptr;
     }
+    static const bool dbg = getenv("Q3_DEBUG_TIMING") != nullptr;
+    struct timespec t0, t1, t2, t3, t4;
+    if (dbg) clock_gettime(CLOCK_MONOTONIC, &t0);
     if (hipSetDevice(e->device) != hipSuccess) { fail(Q3_ERR_HIP, "hipSetDevice failed"); return nullptr; }
     if (e->set_state(token, pos) != Q3_OK) return nullptr;
+    if (dbg) clock_gettime(CLOCK_MONOTONIC, &t1);
     if (e->enqueue_forward(false) != Q3_OK) return nullptr;
+    if (dbg) clock_gettime(CLOCK_MONOTONIC, &t2);
     hipError_t err = hipMemcpyAsync(e->h_logits, e->d_logits, 4 * (size_t)e->cfg.vocab_size, hipMemcpyDeviceToHost, e->stream);
+    if (dbg) clock_gettime(CLOCK_MONOTONIC, &t3);
     if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
     if (err != hipSuccess) {
         fail(Q3_ERR_HIP, "forward failed: %s", hipGetErrorString(err));
         return nullptr;
+    }
+    if (dbg) {
+        clock_gettime(CLOCK_MONOTONIC, &t4);
+        auto us = [](const timespec& a, const timespec& b) { return (b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3; };
+        static int n = 0;
+        if (++n % 16 == 0)
+            fprintf(stderr, "[q3] forward: set_state %.1f us, graph launch %.1f us, D2H enqueue %.1f us, sync %.1f us\n",
+                    us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4));
     }
     return e->h_logits;
 }

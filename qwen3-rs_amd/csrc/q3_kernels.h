@@ -421,21 +421,32 @@ __device__ __forceinline__ void stamp(const GemvArgs& a, int idx) {
 // is in flight: vmcnt retires in order, so the prologue can run at vmcnt(#tile loads) under the weight
 // stream.  Up to kProSlots float4 slots per thread are prefetched (n <= 4096); longer vectors load the
 // rest inside the loop.
-constexpr int kProSlots = 4;
+constexpr int kProSlots = 4;          // PRO_NORM: x and norm weight (dim <= 4096 for every listed model)
+constexpr int kProSlotsQuant = 12;    // PRO_QUANT: x only, up to n = 12288 (the 8B hidden size) in one round trip
+template <int PRO> struct ProSlotCount { static constexpr int value = (PRO == PRO_QUANT) ? kProSlotsQuant : kProSlots; };
+template <int PRO>
 struct ProRegs {
-    v4f x[kProSlots];
+    v4f x[ProSlotCount<PRO>::value];
     v4f w[kProSlots];
 };
 
 template <int PRO>
-__device__ __forceinline__ void gemv_prologue_issue(const GemvArgs& a, ProRegs& pr) {
+__device__ __forceinline__ void gemv_prologue_issue(const GemvArgs& a, ProRegs<PRO>& pr) {
     if (PRO == PRO_PREQ) return;
     const int nv = a.n >> 2;
     const int tid = threadIdx.x;
+    if (PRO == PRO_QUANT) {
+        const int nk = (nv + kWG - 1) / kWG;
+#pragma unroll
+        for (int k = 0; k < ProSlotCount<PRO>::value; ++k)
+            if (k < kProSlots || k < nk)          // wave-uniform: long vectors fetch their extra slots in the same round trip
+                pr.x[k] = ((const v4f*)a.in)[min(tid + k * kWG, nv - 1)];
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < kProSlots; ++k) {
         const int v = min(tid + k * kWG, nv - 1);
-        if (PRO == PRO_QUANT || PRO == PRO_NORM) pr.x[k] = ((const v4f*)a.in)[v];
+        if (PRO == PRO_NORM) pr.x[k] = ((const v4f*)a.in)[v];
         if (PRO == PRO_NORM || PRO == PRO_EMBED_NORM) pr.w[k] = ((const v4f*)a.norm_w)[v];
     }
     if (PRO == PRO_EMBED_NORM) {
@@ -488,7 +499,7 @@ __device__ __forceinline__ v4f norm4(v4f w, float f, v4f xv) {
 }
 
 template <int PRO>
-__device__ __forceinline__ void gemv_prologue_finish(const GemvArgs& a, const GemvSmem& sm, const ProRegs& pr) {
+__device__ __forceinline__ void gemv_prologue_finish(const GemvArgs& a, const GemvSmem& sm, const ProRegs<PRO>& pr) {
     const int n = a.n, G = a.group;
     const int nv = n >> 2;          // float4 slots
     const int glanes = G >> 2;      // threads per quantization group
@@ -502,13 +513,13 @@ __device__ __forceinline__ void gemv_prologue_finish(const GemvArgs& a, const Ge
     }
     if (PRO == PRO_QUANT) {
 #pragma unroll
-        for (int k = 0; k < kProSlots; ++k) {      // static indices: pr stays in registers
+        for (int k = 0; k < ProSlotCount<PRO>::value; ++k) {      // static indices: pr stays in registers
             if (k < nk) {
                 const int v = k * kWG + tid;
                 quantize4_to_lds(pr.x[k], v, glanes, v < nv, sm.xq, sm.xs);
             }
         }
-        for (int k = kProSlots; k < nk; ++k) {
+        for (int k = ProSlotCount<PRO>::value; k < nk; ++k) {
             const int v = k * kWG + tid;
             const v4f y = ((const v4f*)a.in)[min(v, nv - 1)];
             quantize4_to_lds(y, v, glanes, v < nv, sm.xq, sm.xs);
@@ -798,7 +809,7 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
     const bool any = cb < nb;
     Tile<RU, JU> TA, TB;
     RowSrc RA, RB;
-    ProRegs pr;
+    ProRegs<PRO> pr;
     gemv_prologue_issue<PRO>(a, pr);          // activation / norm-weight loads go out first ...
     __builtin_amdgcn_sched_barrier(0);        // (pin the issue order: vmcnt retires in order)
     RA = batch_rows(min(cb, nb - 1));         // (idle waves re-read a valid batch; nothing is stored)

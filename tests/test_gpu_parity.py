@@ -147,6 +147,36 @@ def test_attention(ops, oracle, nh, nkv, hd, S, pos):
     assert np.max(np.abs(xb - rb)) <= FAST_TOL and np.max(np.abs(q2 - rq)) <= FAST_TOL
 
 
+def test_attention_long_context(ops, oracle):
+    """pos beyond the LDS score buffer (scores go through the global scratch) and dozens of K/V chunks."""
+    rng = np.random.default_rng(9)
+    nh, nkv, hd, S, pos = 4, 2, 64, 4600, 4500
+    kvd = nkv * hd
+    q = rng.standard_normal(nh * hd).astype(np.float32)
+    K = (rng.standard_normal((S, kvd)) * 0.5).astype(np.float32)
+    V = rng.standard_normal((S, kvd)).astype(np.float32)
+    K[1000:1100] = 0.0                       # never-written rows are attended over as zeros (generation.rs:26-29)
+    V[1000:1100] = 0.0
+    qw = np.ones(hd, np.float32)
+    kw = np.ones(hd, np.float32)
+    rb, rq, rk = oracle.attention(q, K, V, qw, kw, pos, nh, nkv, hd)
+    xb, q2, k2 = ops.attention(q, K, V, qw, kw, pos, nh, nkv, hd, strict=True)
+    assert_biteq(xb, rb, "xb long context")
+    assert_biteq(k2.reshape(S, kvd)[pos], rk.reshape(S, kvd)[pos])
+    xb, _, _ = ops.attention(q, K, V, qw, kw, pos, nh, nkv, hd, strict=False)
+    assert np.max(np.abs(xb - rb)) <= FAST_TOL
+
+
+def test_eager_launch_mode_matches_graph(q3):
+    """Q3_FLAG_NO_GRAPH launches the same kernel chain eagerly: identical logits and tokens."""
+    path = golden_path("tiny-untied.bin")
+    with q3.TransformerBuilder(path).build() as g, q3.TransformerBuilder(path).with_graph(False).build() as e:
+        for pos in range(5):
+            assert_biteq(np.array(g.forward(7, pos), copy=True), np.array(e.forward(7, pos), copy=True), f"pos {pos}")
+        g.reset_kv(); e.reset_kv()
+        assert g.generate_greedy(3, 2, 10) == e.generate_greedy(3, 2, 10)
+
+
 # ---- whole model -------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["tiny", "tiny-untied"])
 def test_forward_matches_golden_fixture(q3, name):
