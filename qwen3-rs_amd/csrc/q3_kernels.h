@@ -21,6 +21,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Developer instrumentation (ablation switches, in-kernel s_memtime timelines) is compiled in only with -DQ3_DEV
+// (`make dev` -> libqwen3_hip_dev.so); the product build carries none of it.
+#ifdef Q3_DEV
+#define Q3_DEV_ABLATE(args, bit) (((args).debug & (bit)) != 0)
+#else
+#define Q3_DEV_ABLATE(args, bit) false
+#endif
+
 namespace q3 {
 
 constexpr int kWG = 256;       // threads per workgroup
@@ -411,10 +419,14 @@ __device__ __forceinline__ void quantize4_to_lds(v4f y, int v_idx, int glanes, b
 // activation and the weight stream that consumes it.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void stamp(const GemvArgs& a, int idx) {
+#ifdef Q3_DEV
     if (a.stamps != nullptr && (int)blockIdx.x == a.stamp_block && threadIdx.x == 0) {
         const unsigned long long t = __builtin_amdgcn_s_memtime();
         a.stamps[idx] = t;
     }
+#else
+    (void)a; (void)idx;
+#endif
 }
 
 // The activation (and RMSNorm weight) loads are ISSUED before the first weight tile and CONSUMED after it
@@ -781,7 +793,7 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
     auto finish = [&](const RowSrc& rs) {
         wave_lds_sync();
         if (lane < rs.cnt) {
-            const float acc = (a.debug & 4) ? term[lane * ng] : ordered_row_sum(term + lane * ng, ng);
+            const float acc = Q3_DEV_ABLATE(a, 4) ? term[lane * ng] : ordered_row_sum(term + lane * ng, ng);
             if (EPI == EPI_STORE || EPI == EPI_QKV) {
                 rs.out[lane] = acc;
             } else if (EPI == EPI_RESID) {
@@ -816,14 +828,14 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
     load_tile(TA, RA, 0);                     // ... then the first weight tile ...
     __builtin_amdgcn_sched_barrier(0);
     stamp(a, 1);
-    if (a.debug & 1) {
+    if (Q3_DEV_ABLATE(a, 1)) {
         for (int i = threadIdx.x; i < (a.n >> 2); i += kWG) ((int*)sm.xq)[i] = 0x01010101;
         for (int i = threadIdx.x; i < a.n / a.group; i += kWG) sm.xs[i] = 1.0f;
         __syncthreads();
     } else
     gemv_prologue_finish<PRO>(a, sm, pr);     // ... and norm + quantize run under the weight loads
     stamp(a, 2);
-    if (any && !(a.debug & 2)) {
+    if (any && !Q3_DEV_ABLATE(a, 2)) {
         for (;;) {
             int nb_ = cb, njt_ = cjt + 1;
             if (njt_ == njt) { njt_ = 0; nb_ = cb + nwaves; }
@@ -988,7 +1000,11 @@ __device__ __forceinline__ void stage_commit(const StageRegs& sr, float* lds, in
     }
 }
 
+#ifdef Q3_DEV
 #define ATT_STAMP(i) do { if (a.stamps != nullptr && blockIdx.x == 3 && threadIdx.x == 0) a.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ATT_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(kWG) void k_attn(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     ATT_STAMP(0);
@@ -1052,7 +1068,7 @@ __global__ __launch_bounds__(kWG) void k_attn(const AttnArgs a) {
         for (int i = tid; i < hd; i += kWG) krow[i] = k_s[i];   // K is normalised + rotated in place in the cache
     if (a.write_q)
         for (int i = tid; i < hd; i += kWG) a.q[(size_t)h * hd + i] = q_s[i];
-    if (a.debug & 8) { if (tid < hd) a.xb[(size_t)h * hd + tid] = q_s[tid]; return; }
+    if (Q3_DEV_ABLATE(a, 8)) { if (tid < hd) a.xb[(size_t)h * hd + tid] = q_s[tid]; return; }
 
     const float scale = 1.0f / sqrtf((float)hd);  // (head_dim as f32).sqrt().recip()
 

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Tiny driver for profiling: device-resident greedy loop on the 0.6B synthetic checkpoint."""
+"""Tiny driver for profiling: device-resident greedy loop on a synthetic checkpoint.
+Q3_STAMPS / Q3_ABLATE need the developer build: make -C qwen3-rs_amd dev; Q3_HIP_LIB=qwen3-rs_amd/libqwen3_hip_dev.so"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "qwen3-rs_amd"))
