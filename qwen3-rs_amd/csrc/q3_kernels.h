@@ -76,8 +76,23 @@ __device__ __forceinline__ float group_max_f32(float v, int lanes) {
     if (lanes >= 4) v = fmaxf(v, dpp_f<0x4E>(v));
     if (lanes >= 8) v = fmaxf(v, dpp_f<0x141>(v));
     if (lanes >= 16) v = fmaxf(v, dpp_f<0x140>(v));
-    if (lanes >= 32) v = fmaxf(v, __shfl_xor(v, 16));
-    if (lanes >= 64) v = fmaxf(v, __shfl_xor(v, 32));
+    if (lanes == 32) v = fmaxf(v, __shfl_xor(v, 16));
+    if (lanes >= 64) {      // every lane of a 16-lane row holds the row result: combine the four rows via v_readlane
+        const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+        const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+        const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+        const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+        v = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+    }
+    return v;
+}
+// compile-time lane count (<= 16): straight-line DPP
+template <int LANES>
+__device__ __forceinline__ float group_max_f32_t(float v) {
+    if (LANES >= 2) v = fmaxf(v, dpp_f<0xB1>(v));
+    if (LANES >= 4) v = fmaxf(v, dpp_f<0x4E>(v));
+    if (LANES >= 8) v = fmaxf(v, dpp_f<0x141>(v));
+    if (LANES >= 16) v = fmaxf(v, dpp_f<0x140>(v));
     return v;
 }
 // tree sum (default mode only: the order differs from the CPU's sequential fold)
@@ -86,8 +101,14 @@ __device__ __forceinline__ float group_sum_f32(float v, int lanes) {
     if (lanes >= 4) v += dpp_f<0x4E>(v);
     if (lanes >= 8) v += dpp_f<0x141>(v);
     if (lanes >= 16) v += dpp_f<0x140>(v);
-    if (lanes >= 32) v += __shfl_xor(v, 16);
-    if (lanes >= 64) v += __shfl_xor(v, 32);
+    if (lanes == 32) v += __shfl_xor(v, 16);
+    if (lanes >= 64) {
+        const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+        const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+        const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+        const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+        v = (r0 + r1) + (r2 + r3);
+    }
     return v;
 }
 
@@ -395,10 +416,12 @@ __device__ __forceinline__ float seq_sum_terms(const float* t, int n, const floa
 
 // quantize 4 consecutive values held by this thread; its quantization group spans `glanes` = G/4
 // consecutive threads (tensor.rs:91-119).  Writes the packed int8 dword and (group leader) the scale.
+template <int GL_T = 0>
 __device__ __forceinline__ void quantize4_to_lds(v4f y, int v_idx, int glanes, bool valid, int8_t* xq, float* xs) {
     float m = fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)));
     if (!valid) m = 0.0f;
-    m = group_max_f32(m, glanes);
+    if (GL_T > 0) { m = group_max_f32_t<GL_T>(m); glanes = GL_T; }
+    else m = group_max_f32(m, glanes);
     const float scale = m / 127.0f;
     if (valid) {
         int q0 = 0, q1 = 0, q2 = 0, q3 = 0;
@@ -510,8 +533,9 @@ __device__ __forceinline__ v4f norm4(v4f w, float f, v4f xv) {
     return y;
 }
 
-template <int PRO>
+template <int PRO, int LPG_T>
 __device__ __forceinline__ void gemv_prologue_finish(const GemvArgs& a, const GemvSmem& sm, const ProRegs<PRO>& pr) {
+    constexpr int GL = (LPG_T > 0 && LPG_T <= 4) ? 4 * LPG_T : 0;   // threads per quantization group, if known
     const int n = a.n, G = a.group;
     const int nv = n >> 2;          // float4 slots
     const int glanes = G >> 2;      // threads per quantization group
@@ -528,13 +552,13 @@ __device__ __forceinline__ void gemv_prologue_finish(const GemvArgs& a, const Ge
         for (int k = 0; k < ProSlotCount<PRO>::value; ++k) {      // static indices: pr stays in registers
             if (k < nk) {
                 const int v = k * kWG + tid;
-                quantize4_to_lds(pr.x[k], v, glanes, v < nv, sm.xq, sm.xs);
+                quantize4_to_lds<GL>(pr.x[k], v, glanes, v < nv, sm.xq, sm.xs);
             }
         }
         for (int k = ProSlotCount<PRO>::value; k < nk; ++k) {
             const int v = k * kWG + tid;
             const v4f y = ((const v4f*)a.in)[min(v, nv - 1)];
-            quantize4_to_lds(y, v, glanes, v < nv, sm.xq, sm.xs);
+            quantize4_to_lds<GL>(y, v, glanes, v < nv, sm.xq, sm.xs);
         }
         __syncthreads();
         return;
@@ -592,7 +616,7 @@ __device__ __forceinline__ void gemv_prologue_finish(const GemvArgs& a, const Ge
                 y = norm4(pr.w[k], f, pr.x[k]);
                 if (a.tap_out != nullptr && blockIdx.x == 0) ((v4f*)a.tap_out)[v] = y;
             }
-            quantize4_to_lds(y, v, glanes, valid, sm.xq, sm.xs);
+            quantize4_to_lds<GL>(y, v, glanes, valid, sm.xq, sm.xs);
         }
     }
     for (int k = kProSlots; k < nk; ++k) {
@@ -603,7 +627,7 @@ __device__ __forceinline__ void gemv_prologue_finish(const GemvArgs& a, const Ge
             y = norm4(((const v4f*)a.norm_w)[v], f, pro_load_x_global<PRO>(a, v));
             if (a.tap_out != nullptr && blockIdx.x == 0) ((v4f*)a.tap_out)[v] = y;
         }
-        quantize4_to_lds(y, v, glanes, valid, sm.xq, sm.xs);
+        quantize4_to_lds<GL>(y, v, glanes, valid, sm.xq, sm.xs);
     }
     __syncthreads();
 }
@@ -680,7 +704,7 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int n = a.n, G = a.group;
-    const int lpg_shift = __builtin_ctz(G >> 4);   // G is a power of two >= 16
+    const int lpg_shift = (LPG_T > 0) ? __builtin_ctz(LPG_T) : __builtin_ctz(G >> 4);   // G is a power of two >= 16
     const int lpg = 1 << lpg_shift;
     const int ng = n / G;
     const int nchunks = n >> 4;
@@ -833,7 +857,7 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
         for (int i = threadIdx.x; i < a.n / a.group; i += kWG) sm.xs[i] = 1.0f;
         __syncthreads();
     } else
-    gemv_prologue_finish<PRO>(a, sm, pr);     // ... and norm + quantize run under the weight loads
+    gemv_prologue_finish<PRO, LPG_T>(a, sm, pr);     // ... and norm + quantize run under the weight loads
     stamp(a, 2);
     if (any && !Q3_DEV_ABLATE(a, 2)) {
         for (;;) {
