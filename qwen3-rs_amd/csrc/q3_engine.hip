@@ -122,6 +122,8 @@ typedef void (*GemvFn)(const GemvArgs);
 struct Launch {
     Family fam;
     bool is_attn = false, is_next = false;
+    int attn_kind = 0;     // 0: single-kernel attention, 1: k_attn_scores, 2: k_attn_out (long-context split)
+    unsigned grid_y = 1;
     GemvFn fn = nullptr;
     GemvArgs ga{};
     AttnArgs aa{};
@@ -189,15 +191,19 @@ struct q3_engine {
     float* h_logits = nullptr;
     State* h_state = nullptr;
     int32_t* h_tokens = nullptr;
-    // launch plan
-    std::vector<Launch> plan;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
+    // launch plans: `plan` (one attention kernel per layer) for short contexts, `plan_long` (scores + out
+    // kernels over many workgroups) once pos >= split_pos; the host knows pos of every forward it enqueues
+    std::vector<Launch> plan, plan_long;
+    hipGraph_t graph = nullptr, graph_long = nullptr;
+    hipGraphExec_t graph_exec = nullptr, graph_long_exec = nullptr;
+    float* d_att_priv = nullptr;
+    int att_stride = 0;
+    int split_pos = 256;
 
     int load(const char* path, uint32_t ctx_len);
     int build_plan();
     int capture();
-    int enqueue_forward(bool eager);
+    int enqueue_forward(bool eager, size_t pos);
     int set_state(size_t token, size_t pos);
     void release();
 };
@@ -206,7 +212,9 @@ namespace {
 
 void launch_one(const Launch& L, q3_engine* e) {
     if (L.is_attn) {
-        hipLaunchKernelGGL(k_attn, dim3(L.grid), dim3(kWG), L.smem, e->stream, L.aa);
+        if (L.attn_kind == 1) hipLaunchKernelGGL(k_attn_scores, dim3(L.grid, L.grid_y), dim3(kWG), L.smem, e->stream, L.aa);
+        else if (L.attn_kind == 2) hipLaunchKernelGGL(k_attn_out, dim3(L.grid, L.grid_y), dim3(kWG), L.smem, e->stream, L.aa);
+        else hipLaunchKernelGGL(k_attn, dim3(L.grid), dim3(kWG), L.smem, e->stream, L.aa);
     } else if (L.is_next) {
         hipLaunchKernelGGL(k_next, dim3(1), dim3(kWG), 0, e->stream, e->d_state, e->d_argmax_slots, e->n_argmax_slots,
                            e->d_out_tokens, e->out_cap);
@@ -256,7 +264,9 @@ GemvShape plan_gemv(int units, int n, int G, bool swiglu, int row_align, int n_c
 void q3_engine::release() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (graph) (void)hipGraphDestroy(graph);
-    void* dptrs[] = {d_argmax_slots, d_stamps, d_blob, d_x, d_q, d_kraw, d_xb, d_hb, d_logits, d_tap, d_key, d_value, d_rope, d_att, d_state, d_out_tokens};
+    if (graph_long_exec) (void)hipGraphExecDestroy(graph_long_exec);
+    if (graph_long) (void)hipGraphDestroy(graph_long);
+    void* dptrs[] = {d_att_priv, d_argmax_slots, d_stamps, d_blob, d_x, d_q, d_kraw, d_xb, d_hb, d_logits, d_tap, d_key, d_value, d_rope, d_att, d_state, d_out_tokens};
     for (void* p : dptrs)
         if (p) (void)hipFree(p);
     if (h_logits) (void)hipHostFree(h_logits);
@@ -427,7 +437,12 @@ int q3_engine::build_plan() {
     const int big_cap = env_int("Q3_WG_PER_CU_LMHEAD", 4);
     const int att_lds_max = env_int("Q3_ATT_LDS_MAX", 4096);
 
-    if (S > att_lds_max) HIP_TRY(hipMalloc((void**)&d_att, 4 * (size_t)cfg.n_heads * S));
+    split_pos = env_int("Q3_ATT_SPLIT_POS", 256);
+    att_stride = (S + 255) & ~255;
+    const int nsl = hd < kSliceW ? 1 : hd / kSliceW;
+    const bool use_att_global = S > att_lds_max;
+    HIP_TRY(hipMalloc((void**)&d_att, 4 * (size_t)cfg.n_heads * att_stride));
+    HIP_TRY(hipMalloc((void**)&d_att_priv, 4 * (size_t)cfg.n_heads * nsl * att_stride));
     if (env_int("Q3_STAMPS", 0)) {
         HIP_TRY(hipMalloc((void**)&d_stamps, 8 * 8 * (size_t)(5 * L + 4)));
         HIP_TRY(hipMemset(d_stamps, 0, 8 * 8 * (size_t)(5 * L + 4)));
@@ -494,7 +509,7 @@ int q3_engine::build_plan() {
             a.k_norm_w = k_ln + (size_t)l * hd;
             a.rope = d_rope;
             a.xb = d_xb;
-            a.att_global = d_att ? d_att : nullptr;
+            a.att_global = use_att_global ? d_att : nullptr;
             a.st = d_state;
             a.pos_override = -1;
             a.n_heads = cfg.n_heads;
@@ -507,7 +522,7 @@ int q3_engine::build_plan() {
             a.stamps = d_stamps ? d_stamps + 8 * plan.size() : nullptr;
             Ln.aa = a;
             Ln.grid = (unsigned)cfg.n_heads;
-            Ln.smem = attn_smem_bytes(hd, d_att ? 0 : S);
+            Ln.smem = attn_smem_bytes(hd, use_att_global ? 0 : S);
             if ((rc = set_max_smem((const void*)k_attn, Ln.smem))) return rc;
             plan.push_back(Ln);
         }
@@ -597,23 +612,48 @@ int q3_engine::build_plan() {
         Ln.is_next = true;
         plan.push_back(Ln);
     }
+    // long-context plan: every attention launch becomes k_attn_scores (heads x T-chunks) + k_attn_out (heads x slices)
+    for (const Launch& L0 : plan) {
+        if (!L0.is_attn) { plan_long.push_back(L0); continue; }
+        Launch A = L0, B = L0;
+        A.attn_kind = 1;
+        A.aa.att_global = d_att;
+        A.aa.att_stride = att_stride;
+        A.aa.q_out = nullptr;
+        A.grid_y = (unsigned)((S + attn_tch(hd) - 1) / attn_tch(hd));
+        A.smem = attn_scores_smem_bytes(hd);
+        B.attn_kind = 2;
+        B.aa.att_global = d_att;
+        B.aa.att_priv = d_att_priv;
+        B.aa.att_stride = att_stride;
+        B.grid_y = (unsigned)nsl;
+        B.smem = attn_out_smem_bytes(hd, S);
+        if ((rc = set_max_smem((const void*)k_attn_scores, A.smem))) return rc;
+        if ((rc = set_max_smem((const void*)k_attn_out, B.smem))) return rc;
+        plan_long.push_back(A);
+        plan_long.push_back(B);
+    }
     return Q3_OK;
 }
 
 int q3_engine::capture() {
     HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-    const int dbl = env_int("Q3_DEBUG_DOUBLE", 0);   // experiment: run every kernel twice (I-cache warm second run)
-    for (const Launch& L : plan) { launch_one(L, this); if (dbl && !L.is_next) launch_one(L, this); }
+    for (const Launch& L : plan) launch_one(L, this);
     HIP_TRY(hipStreamEndCapture(stream, &graph));
     HIP_TRY(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
+    HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    for (const Launch& L : plan_long) launch_one(L, this);
+    HIP_TRY(hipStreamEndCapture(stream, &graph_long));
+    HIP_TRY(hipGraphInstantiate(&graph_long_exec, graph_long, nullptr, nullptr, 0));
     return Q3_OK;
 }
 
-int q3_engine::enqueue_forward(bool eager) {
+int q3_engine::enqueue_forward(bool eager, size_t pos) {
+    const bool lng = (int64_t)pos >= (int64_t)split_pos;
     if (graph_exec && !eager) {
-        HIP_TRY(hipGraphLaunch(graph_exec, stream));
+        HIP_TRY(hipGraphLaunch(lng ? graph_long_exec : graph_exec, stream));
     } else {
-        for (const Launch& L : plan) launch_one(L, this);
+        for (const Launch& L : (lng ? plan_long : plan)) launch_one(L, this);
         HIP_TRY(hipGetLastError());
     }
     return Q3_OK;
@@ -694,7 +734,7 @@ const float* q3_forward(q3_engine* e, size_t token, size_t pos) {
     if (hipSetDevice(e->device) != hipSuccess) { fail(Q3_ERR_HIP, "hipSetDevice failed"); return nullptr; }
     if (e->set_state(token, pos) != Q3_OK) return nullptr;
     if (dbg) clock_gettime(CLOCK_MONOTONIC, &t1);
-    if (e->enqueue_forward(false) != Q3_OK) return nullptr;
+    if (e->enqueue_forward(false, pos) != Q3_OK) return nullptr;
     if (dbg) clock_gettime(CLOCK_MONOTONIC, &t2);
     hipError_t err = hipMemcpyAsync(e->h_logits, e->d_logits, 4 * (size_t)e->cfg.vocab_size, hipMemcpyDeviceToHost, e->stream);
     if (dbg) clock_gettime(CLOCK_MONOTONIC, &t3);
@@ -720,7 +760,7 @@ int q3_forward_argmax(q3_engine* e, size_t token, size_t pos, int32_t* next_toke
     HIP_TRY(hipSetDevice(e->device));
     int rc = e->set_state(token, pos);
     if (rc) return rc;
-    if ((rc = e->enqueue_forward(false))) return rc;
+    if ((rc = e->enqueue_forward(false, pos))) return rc;
     HIP_TRY(hipMemcpyAsync(e->h_tokens, e->d_out_tokens, 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     *next_token = e->h_tokens[0];
@@ -739,7 +779,7 @@ int q3_generate_greedy(q3_engine* e, size_t first_token, size_t first_pos, size_
     struct timespec t0, t1, t2;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (size_t k = 0; k < n_tokens; ++k)
-        if ((rc = e->enqueue_forward(false))) return rc;
+        if ((rc = e->enqueue_forward(false, first_pos + k))) return rc;
     clock_gettime(CLOCK_MONOTONIC, &t1);
     HIP_TRY(hipMemcpyAsync(e->h_tokens, e->d_out_tokens, 4 * n_tokens, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -801,7 +841,8 @@ int q3_profile(q3_engine* e, size_t token, size_t pos, int reps, float* ms, int3
     if (!e || !ms || !launches || cap < F_COUNT || reps <= 0) return fail(Q3_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(e->device));
     for (int i = 0; i < cap; ++i) { ms[i] = 0.f; launches[i] = 0; }
-    const size_t nl = e->plan.size();
+    const std::vector<Launch>& P = ((int64_t)pos >= (int64_t)e->split_pos) ? e->plan_long : e->plan;
+    const size_t nl = P.size();
     std::vector<hipEvent_t> ev(2 * F_COUNT);
     for (auto& x : ev) HIP_TRY(hipEventCreate(&x));
     for (int r = 0; r < reps; ++r) {
@@ -810,11 +851,11 @@ int q3_profile(q3_engine* e, size_t token, size_t pos, int reps, float* ms, int3
         // one full forward first so every family runs on live data, then each family's launches back to back
         // between ONE pair of events: the average is the launch period (kernel + boundary), the same quantity
         // rocprofv3's per-dispatch durations sum to on a serialised stream.
-        for (size_t i = 0; i < nl; ++i) if (!e->plan[i].is_next) launch_one(e->plan[i], e);
+        for (size_t i = 0; i < nl; ++i) if (!P[i].is_next) launch_one(P[i], e);
         for (int f = 0; f < F_COUNT; ++f) {
             HIP_TRY(hipEventRecord(ev[2 * f], e->stream));
             for (size_t i = 0; i < nl; ++i)
-                if (e->plan[i].fam == f) { launch_one(e->plan[i], e); launches[f] += 1; }
+                if (P[i].fam == f) { launch_one(P[i], e); launches[f] += 1; }
             HIP_TRY(hipEventRecord(ev[2 * f + 1], e->stream));
         }
         HIP_TRY(hipStreamSynchronize(e->stream));
@@ -998,8 +1039,13 @@ int q3_op_attention(float* xb, float* q, float* key_cache_layer, const float* va
             tab[p * head_dim + 2 * i + 1] = sinf(angle);
         }
     if ((rc = drope.upload(tab.data(), 4 * tab.size()))) return rc;
-    const bool att_global = seq_len > 4096;
-    if (att_global && (rc = datt.alloc(4 * n_heads * seq_len))) return rc;
+    const bool split = pos >= 256;                       // same rule as the engine's long-context plan
+    const bool att_global = split || seq_len > 4096;
+    const int att_stride = (int)((seq_len + 255) & ~(size_t)255);
+    const int nsl = head_dim < (size_t)kSliceW ? 1 : (int)(head_dim / kSliceW);
+    DevBuf dpriv, dqout;
+    if (att_global && (rc = datt.alloc(4 * n_heads * (size_t)att_stride))) return rc;
+    if (split && ((rc = dpriv.alloc(4 * n_heads * nsl * (size_t)att_stride)) || (rc = dqout.alloc(4 * ahd)))) return rc;
     AttnArgs a{};
     a.q = dq.as<float>();
     a.key_cache = dk.as<float>();
@@ -1019,9 +1065,22 @@ int q3_op_attention(float* xb, float* q, float* key_cache_layer, const float* va
     a.strict = (flags & Q3_FLAG_FAST) ? 0 : 1;
     a.write_q = 1;
     a.stamps = nullptr;
-    const size_t smem = attn_smem_bytes((int)head_dim, att_global ? 0 : (int)seq_len);
-    if ((rc = set_max_smem((const void*)k_attn, smem))) return rc;
-    hipLaunchKernelGGL(k_attn, dim3((unsigned)n_heads), dim3(kWG), smem, 0, a);
+    if (split) {
+        a.att_stride = att_stride;
+        a.att_priv = dpriv.as<float>();
+        a.q_out = dqout.as<float>();
+        const size_t sm1 = attn_scores_smem_bytes((int)head_dim), sm2 = attn_out_smem_bytes((int)head_dim, (int)seq_len);
+        if ((rc = set_max_smem((const void*)k_attn_scores, sm1)) || (rc = set_max_smem((const void*)k_attn_out, sm2))) return rc;
+        const unsigned nchunk = (unsigned)((seq_len + attn_tch((int)head_dim) - 1) / attn_tch((int)head_dim));
+        hipLaunchKernelGGL(k_attn_scores, dim3((unsigned)n_heads, nchunk), dim3(kWG), sm1, 0, a);
+        hipLaunchKernelGGL(k_attn_out, dim3((unsigned)n_heads, (unsigned)nsl), dim3(kWG), sm2, 0, a);
+        if ((rc = op_end())) return rc;
+        HIP_TRY(hipMemcpy(dq.p, dqout.p, 4 * ahd, hipMemcpyDeviceToDevice));
+    } else {
+        const size_t smem = attn_smem_bytes((int)head_dim, att_global ? 0 : (int)seq_len);
+        if ((rc = set_max_smem((const void*)k_attn, smem))) return rc;
+        hipLaunchKernelGGL(k_attn, dim3((unsigned)n_heads), dim3(kWG), smem, 0, a);
+    }
     if ((rc = op_end())) return rc;
     HIP_TRY(hipMemcpy(xb, dxb.p, 4 * ahd, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(q, dq.p, 4 * ahd, hipMemcpyDeviceToHost));

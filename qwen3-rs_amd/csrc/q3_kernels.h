@@ -347,21 +347,15 @@ __device__ __forceinline__ int term_index(int i, int n) {
     return (i / kSpecBlen) * (kSpecBlen + kSpecPad) + (i % kSpecBlen);
 }
 
-// every lane returns the exact sequential sum of the n terms stored (term_index layout) at t
-__device__ __forceinline__ float seq_sum_terms(const float* t, int n, const float* approx_tot = nullptr) {
-    if (!spec_ok(n)) {
-        if ((n & 3) == 0) return seq_chain(-0.0f, (const v4f*)t, n >> 2);
-        float s = -0.0f;
-        for (int i = 0; i < n; ++i) s = s + t[i];
-        return s;
-    }
-    const int nblk = n / kSpecBlen;                     // 8..64 blocks, lane j folds block j
-    constexpr int nq = kSpecBlen >> 2;
+// Exact sequential sum of nblk (<= 64) consecutive blocks of blen terms (blen % 4 == 0); block j starts at
+// t + j*stride (16-byte aligned).  Every lane returns the sum.  approx_tot: optional nblk approximate block totals.
+__device__ __forceinline__ float seq_sum_blocks(const float* t, int nblk, int blen, int stride, const float* approx_tot) {
+    const int nq = blen >> 2;
     const int j = threadIdx.x & 63;
     const bool live = j < nblk;
-    const v4f* blk = (const v4f*)(t + (live ? j : 0) * (kSpecBlen + kSpecPad));
-    // inclusive scan over the wave: DPP row_shr within the 16-lane rows, then the row totals of the rows below
-    // (v_readlane).  Only used for guesses and corrections, whose exactness is verified afterwards.
+    const v4f* blk = (const v4f*)(t + (size_t)(live ? j : 0) * stride);
+    // inclusive scan over the wave: DPP row_shr within the 16-lane rows, then the row totals of the rows below.
+    // Only used for guesses and corrections, whose exactness is verified afterwards.
     auto wave_scan = [&](float v) {
         v += dpp_f<0x111>(v);
         v += dpp_f<0x112>(v);
@@ -374,8 +368,7 @@ __device__ __forceinline__ float seq_sum_terms(const float* t, int n, const floa
         else if (row == 3) v += (r0 + r1) + r2;
         return v;
     };
-    // previous lane's value across the whole wave (row_shr:1 does not cross DPP rows)
-    auto prev_lane = [&](float v) { return __shfl_up(v, 1); };
+    auto prev_lane = [&](float v) { return __shfl_up(v, 1); };   // row_shr:1 does not cross DPP rows
     // approximate block totals: only a guess, any summation order will do
     float tot = 0.0f;
     if (approx_tot != nullptr) {
@@ -412,6 +405,17 @@ __device__ __forceinline__ float seq_sum_terms(const float* t, int n, const floa
         if (__all(ok)) break;
     }
     return __shfl(out, nblk - 1);   // the last block's output
+}
+
+// every lane returns the exact sequential sum of the n terms stored (term_index layout) at t
+__device__ __forceinline__ float seq_sum_terms(const float* t, int n, const float* approx_tot = nullptr) {
+    if (!spec_ok(n)) {
+        if ((n & 3) == 0) return seq_chain(-0.0f, (const v4f*)t, n >> 2);
+        float s = -0.0f;
+        for (int i = 0; i < n; ++i) s = s + t[i];
+        return s;
+    }
+    return seq_sum_blocks(t, n / kSpecBlen, kSpecBlen, kSpecBlen + kSpecPad, approx_tot);
 }
 
 // quantize 4 consecutive values held by this thread; its quantization group spans `glanes` = G/4
@@ -932,6 +936,9 @@ struct AttnArgs {
     int n_heads, n_kv_heads, hd, seq_len;
     int strict;
     int write_q;              // also write the normalised q back (operator-level parity)
+    float* q_out;             // split path: normalised q goes here (other chunk workgroups still read the raw q)
+    float* att_priv;          // split path: [n_heads][slices][att_stride] private probability rows of k_attn_out
+    int att_stride;           // floats per score row (>= seq_len rounded up to 256)
     int debug;                // ablation: 8 = return right after the q/k norm+rope
     unsigned long long* stamps;   // developer timeline (block 0, thread 0)
 };
@@ -1241,6 +1248,248 @@ __global__ __launch_bounds__(kWG) void k_attn(const AttnArgs a) {
         for (int i = tid; i < hd; i += kWG) {
             float r = opart[i];
             for (int w = 1; w < kWaves; ++w) r = r + opart[w * hd + i];
+            out[i] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Long-context attention (pos >= the host's split threshold): the same arithmetic, in the same order, spread
+// over more workgroups.  k_attn_scores: grid (heads, T-chunks) -- every chunk's dots are independent.
+// k_attn_out: grid (heads, hd/32) -- softmax is recomputed per slice (cheap), the V accumulation is one
+// sequential chain per output element and element slices are independent, so both stay in reference order.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSliceW = 32;    // output elements per k_attn_out workgroup
+constexpr int kVChunk = 256;   // timesteps of V staged per LDS round in k_attn_out
+constexpr int kPLds = 8192;    // probability rows up to this length live in LDS (32 KiB); longer ones go through HBM/L2
+
+__host__ __device__ inline size_t attn_scores_smem_bytes(int hd) {
+    return 4 * ((size_t)hd * 6 + 64 + (size_t)attn_tch(hd) * (hd + kKPad));
+}
+__host__ __device__ inline size_t attn_out_smem_bytes(int hd, int seq_len) {
+    const int w = hd < kSliceW ? hd : kSliceW;
+    const int pl = ((seq_len + 255) & ~255) <= kPLds ? ((seq_len + 255) & ~255) : 0;
+    return 4 * ((size_t)kVChunk * w + kVChunk + 64 + (size_t)kWaves * w + (size_t)pl);
+}
+
+__global__ __launch_bounds__(kWG) void k_attn_scores(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int hd = a.hd, tch = attn_tch(hd), kld = hd + kKPad;
+    float* q_s = (float*)smem_raw;
+    float* k_s = q_s + hd;
+    float* raw = k_s + hd;
+    float* sq = raw + 2 * hd;
+    float* red = sq + 2 * hd;
+    float* kbuf = red + 64;
+
+    const int h = blockIdx.x, c = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kv_mul = a.n_heads / a.n_kv_heads, kvh = h / kv_mul;
+    const size_t kvd = (size_t)a.n_kv_heads * hd;
+    const int pos = a.pos_override >= 0 ? a.pos_override : a.st->pos;
+    const int np = pos + 1;
+    const int t0 = c * tch;
+    if (t0 >= np) return;                              // chunks beyond the current position: nothing to do
+    const int cnt = min(tch, np - t0);
+    const bool has_pos = pos < t0 + cnt;               // the chunk that contains the current position
+    const float* cs = a.rope + (size_t)pos * hd;
+    const float* kbase = a.key_cache + (size_t)kvh * hd;
+    float* att = a.att_global + (size_t)h * a.att_stride;
+
+    float rq = 0.f, rk = 0.f;
+    if (tid < hd) {
+        rq = a.q[(size_t)h * hd + tid];
+        if (has_pos) rk = a.k_raw[(size_t)kvh * hd + tid];
+    }
+    StageRegs sk;
+    RopeRegs rr;
+    rope_regs_load(rr, wave == 0 ? a.q_norm_w : a.k_norm_w, cs, hd);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_issue(sk, kbase, kvd, t0, cnt, hd);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid < hd) { raw[tid] = rq; raw[hd + tid] = rk; }
+    __syncthreads();
+    if (wave == 0) wave_norm_rope(q_s, raw, sq, rr, hd, a.strict);
+    else if (wave == 1 && has_pos) wave_norm_rope(k_s, raw + hd, sq + hd, rr, hd, a.strict);
+    stage_commit(sk, kbuf, kld, t0, cnt, hd, pos);
+    __syncthreads();
+    if (has_pos) {
+        for (int i = tid; i < hd; i += kWG) kbuf[(pos - t0) * kld + i] = k_s[i];
+        if (h % kv_mul == 0) {
+            float* kdst = a.key_cache + (size_t)pos * kvd + (size_t)kvh * hd;
+            for (int i = tid; i < hd; i += kWG) kdst[i] = k_s[i];
+        }
+    }
+    if (a.q_out != nullptr && c == 0)
+        for (int i = tid; i < hd; i += kWG) a.q_out[(size_t)h * hd + i] = q_s[i];
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)hd);
+    if (a.strict) {
+        for (int t = tid; t < cnt; t += kWG) {
+            const v4f* k4 = (const v4f*)(kbuf + t * kld);
+            const v4f* q4 = (const v4f*)q_s;
+            float dot = -0.0f;
+            const int nq = hd >> 2;
+            int i = 0;
+            for (; i + 16 <= nq; i += 16) {
+                v4f kk[16], qq[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { kk[u] = k4[i + u]; qq[u] = q4[i + u]; }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    float p = qq[u].x * kk[u].x; dot = dot + p;
+                    p = qq[u].y * kk[u].y; dot = dot + p;
+                    p = qq[u].z * kk[u].z; dot = dot + p;
+                    p = qq[u].w * kk[u].w; dot = dot + p;
+                }
+            }
+            for (; i < nq; ++i) {
+                const v4f kv = k4[i], qv = q4[i];
+                float p = qv.x * kv.x; dot = dot + p;
+                p = qv.y * kv.y; dot = dot + p;
+                p = qv.z * kv.z; dot = dot + p;
+                p = qv.w * kv.w; dot = dot + p;
+            }
+            att[t0 + t] = dot * scale;
+        }
+    } else {
+        const int lpt = hd >> 2, tpw = 64 / lpt;
+        const int sub = lane / lpt, li = lane % lpt;
+        const v4f qv = *(const v4f*)(q_s + 4 * li);
+        for (int tb = wave * tpw; tb < cnt; tb += kWaves * tpw) {
+            const int t = tb + sub;
+            float p = 0.0f;
+            if (t < cnt) {
+                const v4f kv = *(const v4f*)(kbuf + t * kld + 4 * li);
+                p = qv.x * kv.x;
+                p = p + qv.y * kv.y;
+                p = p + qv.z * kv.z;
+                p = p + qv.w * kv.w;
+            }
+            p = group_sum_f32(p, lpt);
+            if (t < cnt && li == 0) att[t0 + t] = p * scale;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int hd = a.hd;
+    const int w = hd < kSliceW ? hd : kSliceW;          // slice width (power of two >= 8)
+    float* vbuf = (float*)smem_raw;                      // [kVChunk][w]
+    float* pbuf = vbuf + kVChunk * w;                    // [kVChunk]
+    float* red = pbuf + kVChunk;                         // [64]
+    float* opart = red + 64;                             // [kWaves][w]
+    float* p_lds = opart + kWaves * w;                   // [npad] when the row fits (see attn_out_smem_bytes)
+
+    const int h = blockIdx.x, sl = blockIdx.y, nsl = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kv_mul = a.n_heads / a.n_kv_heads, kvh = h / kv_mul;
+    const size_t kvd = (size_t)a.n_kv_heads * hd;
+    const int pos = a.pos_override >= 0 ? a.pos_override : a.st->pos;
+    const int np = pos + 1;
+    const int npad = (np + 255) & ~255;                  // whole 64 x (npad/64) blocks for the exact sum
+    const float* src = a.att_global + (size_t)h * a.att_stride;
+    const bool p_in_lds = ((a.seq_len + 255) & ~255) <= kPLds;
+    float* p = p_in_lds ? p_lds : a.att_priv + ((size_t)h * nsl + sl) * a.att_stride;
+    const float* vbase = a.value_cache + (size_t)kvh * hd + (size_t)sl * w;
+
+    // ---- softmax (layers.rs:495-506) into this workgroup's private probability row
+    float m = -__builtin_inff();
+    for (int t = tid; t < np; t += kWG) m = fmaxf(m, src[t]);
+    m = block_max(m, red);
+    float part = 0.0f;
+    for (int t = tid; t < npad; t += kWG) {
+        float e = 0.0f;                                  // +0.0 padding leaves every partial sum unchanged
+        if (t < np) { e = q3_expf(src[t] - m); part = part + e; }
+        p[t] = e;
+    }
+    __syncthreads();
+    float sum;
+    if (a.strict) sum = seq_sum_blocks(p, 64, npad >> 6, npad >> 6, nullptr);
+    else sum = block_sum_fast(part, red);
+    const float inv = 1.0f / sum;
+    __syncthreads();
+    for (int t = tid; t < np; t += kWG) p[t] = p[t] * inv;
+    __syncthreads();
+
+    // ---- out[e] = sum_t p[t] * V[t][e]  (layers.rs:406-417), V slices staged kVChunk timesteps at a time
+    const int w4s = __builtin_ctz(w >> 2);               // float4 per slice row = 1 << w4s
+    const int rps = kWG >> w4s;                          // rows per staging pass of the whole workgroup
+    const int npass = (kVChunk + rps - 1) / rps;         // <= 8 (w = 32) ... 2 (w = 8)
+    const int r0 = tid >> w4s, c4 = tid & ((1 << w4s) - 1);
+    float o_s = 0.0f;
+    v4f o_f = {0.f, 0.f, 0.f, 0.f};
+    const int lpt = w >> 2, tpw = 64 / lpt;              // default mode: lanes per timestep / timesteps per wave step
+    const int sub = lane / lpt, li = lane % lpt;
+    v4f vreg[8];
+    auto v_issue = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (u < npass) {
+                const int t = min(c0 + r0 + u * rps, np - 1);
+                vreg[u] = *(const v4f*)(vbase + (size_t)t * kvd + 4 * c4);
+            }
+        }
+    };
+    auto v_commit = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + u * rps;
+            if (u < npass && r < kVChunk && c0 + r < np) *(v4f*)(vbuf + r * w + 4 * c4) = vreg[u];
+        }
+        for (int t = tid; t < kVChunk; t += kWG) pbuf[t] = (c0 + t < np) ? p[c0 + t] : 0.0f;
+    };
+    v_issue(0);
+    for (int c0 = 0; c0 < np; c0 += kVChunk) {
+        const int cnt = min(kVChunk, np - c0);
+        __syncthreads();                                 // previous chunk fully consumed
+        v_commit(c0);
+        __syncthreads();
+        if (c0 + kVChunk < np) v_issue(c0 + kVChunk);     // next chunk in flight while this one is folded
+        if (a.strict) {
+            if (tid < w) {
+                const float* v = vbuf + tid;
+                int t = 0;
+                for (; t + 16 <= cnt; t += 16) {
+                    float vv[16], ww[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) { vv[u] = v[(t + u) * w]; ww[u] = pbuf[t + u]; }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) { const float pr = ww[u] * vv[u]; o_s = o_s + pr; }
+                }
+                for (; t < cnt; ++t) { const float pr = pbuf[t] * v[t * w]; o_s = o_s + pr; }
+            }
+        } else {
+            for (int tb = wave * tpw; tb < cnt; tb += kWaves * tpw) {
+                const int t = tb + sub;
+                if (t < cnt) {
+                    const float wt = pbuf[t];
+                    const v4f vv = *(const v4f*)(vbuf + t * w + 4 * li);
+                    o_f.x = o_f.x + wt * vv.x;
+                    o_f.y = o_f.y + wt * vv.y;
+                    o_f.z = o_f.z + wt * vv.z;
+                    o_f.w = o_f.w + wt * vv.w;
+                }
+            }
+        }
+    }
+    float* out = a.xb + (size_t)h * hd + (size_t)sl * w;
+    if (a.strict) {
+        if (tid < w) out[tid] = o_s;
+    } else {
+        for (int msk = lpt; msk < 64; msk <<= 1) {
+            o_f.x += __shfl_xor(o_f.x, msk);
+            o_f.y += __shfl_xor(o_f.y, msk);
+            o_f.z += __shfl_xor(o_f.z, msk);
+            o_f.w += __shfl_xor(o_f.w, msk);
+        }
+        __syncthreads();
+        if (sub == 0) *(v4f*)(opart + wave * w + 4 * li) = o_f;
+        __syncthreads();
+        for (int i = tid; i < w; i += kWG) {
+            float r = opart[i];
+            for (int ww = 1; ww < kWaves; ++ww) r = r + opart[ww * w + i];
             out[i] = r;
         }
     }

@@ -104,6 +104,7 @@ SHAPES: Dict[str, ModelShape] = {
     "tiny-untied": ModelShape(128, 192, 3, 4, 4, 320, 48, 32, False, 32),
     "tiny-g64": ModelShape(256, 384, 2, 4, 2, 512, 96, 64, True, 64),
     "small-hd128": ModelShape(512, 1024, 3, 8, 4, 2048, 256, 128, True, 64),
+    "small-longctx": ModelShape(256, 512, 2, 4, 2, 512, 2048, 64, True, 64),
     # the real 4B / 8B layer dimensions with 2 layers and a reduced vocabulary: parity-test cases for
     # BASELINE configs 3-5 that the CPU oracle finishes in seconds (n = 2560, 9728, 4096, 12288; kv_mul 4)
     "qwen3-4b-dims-l2": ModelShape(2560, 9728, 2, 32, 8, 16384, 4096, 128, True, 64),

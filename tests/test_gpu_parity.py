@@ -253,6 +253,35 @@ def test_big_layer_dims_vs_oracle(q3, oracle, name):
         assert t.generate_greedy(tok, 9, 3) == want
 
 
+def test_long_context_split_attention_vs_oracle(q3, oracle, tmp_ckpt_dir):
+    """pos >= 256 switches the engine to the long-context launch plan (scores over heads x T-chunks, softmax + V over
+    heads x element slices).  Logits stay bit-identical across the switch, at chunk boundaries and deep into the
+    context; the device-resident greedy loop crosses the threshold mid-run."""
+    ck = q3.checkpoint
+    path = os.path.join(tmp_ckpt_dir, "small-longctx.bin")
+    ck.ensure_synthetic_checkpoint(path, ck.SHAPES["small-longctx"], seed=5)
+    om = oracle.OracleModel(path)
+    with q3.TransformerBuilder(path).build() as t:
+        tok = 7
+        for pos in [0, 1, 254, 255, 256, 257, 383, 384, 385, 700, 1500, 2047, 300]:
+            a = np.array(t.forward(tok, pos), copy=True)
+            b = om.forward(tok, pos)
+            assert_biteq(a, b, f"pos {pos}")
+            tok = oracle.sample_argmax(b)
+        t.reset_kv()
+        om.reset()
+        want, ot = [], 11
+        for p in range(250, 262):
+            ot = oracle.sample_argmax(om.forward(ot, p))
+            want.append(ot)
+        assert t.generate_greedy(11, 250, 12) == want
+    with q3.TransformerBuilder(path).with_strict(False).build() as t:      # opt-in tree mode through the split path
+        om.reset()
+        for pos in (300, 301, 900):
+            a, b = np.array(t.forward(3, pos), copy=True), om.forward(3, pos)
+            assert np.max(np.abs(a - b)) <= 2e-5
+
+
 def test_engine_error_behaviour(q3, tmp_ckpt_dir):
     """Same failure surface as TransformerBuilder::build / forward in the reference."""
     with pytest.raises(q3.Q3Error, match="Failed to open checkpoint"):
