@@ -79,6 +79,77 @@ __global__ __launch_bounds__(256) void k_bgemm(const int8_t* __restrict__ w, con
     for (int r = 0; r < 4; ++r) out[(size_t)(sb * 16 + i) * d + rb * 16 + 4 * kq + r] = acc[r];
 }
 
+
+// variant 2: one wave = 16 rows x (NSB x 16) streams: the weight fragment and its scales are loaded once and fed to
+// NSB MFMAs; 4*NSB accumulators per lane.
+template <int KS, int NSB>
+__global__ __launch_bounds__(256) void k_bgemm2(const int8_t* __restrict__ w, const float* __restrict__ ws,
+                                                const int8_t* __restrict__ xq, const float* __restrict__ xs,
+                                                float* __restrict__ out, int n, int d, int B) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rb = blockIdx.x * 4 + wave;
+    if (rb * 16 >= d) return;
+    const int ng = n / G;
+    const int i = lane & 15, kq = lane >> 4;
+    const int8_t* wrow = w + (size_t)(rb * 16 + i) * n + 16 * kq;
+    const float* wsr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wsr[r] = ws + (size_t)(rb * 16 + 4 * kq + r) * ng;
+    float acc[NSB][4];
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[sb][r] = -0.0f;
+    struct Step { v4i a[KS], b[NSB][KS]; v4f ws[4][KS / 4], xs[NSB][KS / 4]; };
+    Step s0, s1;
+    auto load = [&](Step& s, int g0) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const int g = min(g0 + k, ng - 1);
+            s.a[k] = __builtin_nontemporal_load((const v4i*)(wrow + (size_t)g * G));
+#pragma unroll
+            for (int sb = 0; sb < NSB; ++sb) s.b[sb][k] = *(const v4i*)(xq + (size_t)(sb * 16 + i) * n + 16 * kq + (size_t)g * G);
+        }
+#pragma unroll
+        for (int q = 0; q < KS / 4; ++q) {
+            const int g = min(g0 + 4 * q, ng - 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s.ws[r][q] = __builtin_nontemporal_load((const v4f*)(wsr[r] + g));
+#pragma unroll
+            for (int sb = 0; sb < NSB; ++sb) s.xs[sb][q] = *(const v4f*)(xs + (size_t)(sb * 16 + i) * ng + g);
+        }
+    };
+    auto compute = [&](const Step& s, int g0) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            if (g0 + k < ng) {
+#pragma unroll
+                for (int sb = 0; sb < NSB; ++sb) {
+                    const v4i c = __builtin_amdgcn_mfma_i32_16x16x64_i8(s.a[k], s.b[sb][k], (v4i){0, 0, 0, 0}, 0, 0, 0);
+                    const float xsc = s.xs[sb][k / 4][k % 4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float t = (float)c[r] * s.ws[r][k / 4][k % 4];
+                        t = t * xsc;
+                        acc[sb][r] = acc[sb][r] + t;
+                    }
+                }
+            }
+        }
+    };
+    load(s0, 0);
+    for (int g0 = 0; g0 < ng; g0 += 2 * KS) {
+        load(s1, g0 + KS);
+        compute(s0, g0);
+        load(s0, g0 + 2 * KS);
+        compute(s1, g0 + KS);
+    }
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(size_t)(sb * 16 + i) * d + rb * 16 + 4 * kq + r] = acc[sb][r];
+}
+
 static void cpu_ref(const std::vector<int8_t>& w, const std::vector<float>& ws, const std::vector<int8_t>& xq,
                     const std::vector<float>& xs, std::vector<float>& out, int n, int d, int B) {
     const int ng = n / G;
@@ -96,7 +167,7 @@ static void cpu_ref(const std::vector<int8_t>& w, const std::vector<float>& ws, 
         }
 }
 
-template <int KS>
+template <int KS, int VAR = 1>
 static void run(int n, int d, int B, bool check) {
     const int ng = n / G;
     const size_t copies = check ? 1 : std::min<size_t>(8, (600ull << 20) / ((size_t)n * d) + 1);
@@ -116,9 +187,9 @@ static void run(int n, int d, int B, bool check) {
     }
     CK(hipMemcpy(dx, hx.data(), hx.size(), hipMemcpyHostToDevice));
     CK(hipMemcpy(dxs, hxs.data(), 4 * hxs.size(), hipMemcpyHostToDevice));
-    const int tasks = (d / 16) * (B / 16);
+    const int tasks = VAR == 2 ? (d / 16) : (d / 16) * (B / 16);
     const int grid = (tasks + 3) / 4;
-    auto launch = [&](int i) { hipLaunchKernelGGL(k_bgemm<KS>, grid, 256, 0, 0, dw + (i % copies) * hw.size(), dws + (i % copies) * hws.size(), dx, dxs, dout, n, d, B); };
+    auto launch = [&](int i) { if (VAR == 2) { hipLaunchKernelGGL((k_bgemm2<KS, 2>), grid, 256, 0, 0, dw + (i % copies) * hw.size(), dws + (i % copies) * hws.size(), dx, dxs, dout, n, d, B); return; } hipLaunchKernelGGL(k_bgemm<KS>, grid, 256, 0, 0, dw + (i % copies) * hw.size(), dws + (i % copies) * hws.size(), dx, dxs, dout, n, d, B); };
     launch(0);
     CK(hipDeviceSynchronize());
     if (check) {
@@ -126,14 +197,14 @@ static void run(int n, int d, int B, bool check) {
         cpu_ref(hw, hws, hx, hxs, href, n, d, B);
         size_t bad = 0;
         for (size_t k = 0; k < hout.size(); ++k) bad += memcmp(&hout[k], &href[k], 4) != 0;
-        printf("check n=%d d=%d B=%d KS=%d: %zu / %zu outputs differ bitwise\n", n, d, B, KS, bad, hout.size());
+        printf("check var=%d n=%d d=%d B=%d KS=%d: %zu / %zu outputs differ bitwise\n", VAR, n, d, B, KS, bad, hout.size());
     } else {
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         const int reps = 30;
         CK(hipEventRecord(e0)); for (int i = 0; i < reps; ++i) launch(i); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         const double bytes = (double)n * d * (1.0 + 4.0 / G);
-        printf("n=%5d d=%6d B=%d KS=%d grid=%d: %.2f us  %.2f TB/s (weights)  %.0f tok-rows/us\n", n, d, B, KS, grid, ms * 1e3 / reps,
+        printf("var=%d n=%5d d=%6d B=%d KS=%d grid=%d: %.2f us  %.2f TB/s (weights)  %.0f tok-rows/us\n", VAR, n, d, B, KS, grid, ms * 1e3 / reps,
                bytes / (ms * 1e-3 / reps) / 1e12, 0.0);
     }
     hipFree(dw); hipFree(dx); hipFree(dws); hipFree(dxs); hipFree(dout);
@@ -143,9 +214,11 @@ int main() {
     run<4>(256, 64, 32, true);
     run<4>(1024, 48, 16, true);
     run<8>(2048, 32, 32, true);
+    run<4, 2>(2048, 64, 32, true);
     for (auto nd : {std::pair<int,int>{4096, 12288}, {4096, 4096}, {12288, 4096}, {4096, 151936}, {1024, 151936}}) {
         run<4>(nd.first, nd.second, 32, false);
-        run<8>(nd.first, nd.second, 32, false);
+        run<4, 2>(nd.first, nd.second, 32, false);
+        run<8, 2>(nd.first, nd.second, 32, false);
     }
     return 0;
 }
