@@ -282,6 +282,23 @@ def test_long_context_split_attention_vs_oracle(q3, oracle, tmp_ckpt_dir):
             assert np.max(np.abs(a - b)) <= 2e-5
 
 
+def test_two_engines_are_independent(q3):
+    """Replicas: engines share nothing (own stream, KV cache, scratch, graphs).  Interleaving two engines -- here on one
+    device -- gives each exactly the tokens it produces alone."""
+    pa, pb = golden_path("tiny.bin"), golden_path("tiny-untied.bin")
+    with q3.TransformerBuilder(pa).build() as a, q3.TransformerBuilder(pb).build() as b:
+        solo_a = a.generate_greedy(5, 2, 20)
+        solo_b = b.generate_greedy(9, 0, 20)
+        a.reset_kv(); b.reset_kv()
+        ta, tb, ia, ib = 5, 9, [], []
+        for k in range(20):                      # strictly alternating forward_argmax calls
+            ta = a.forward_argmax(ta, 2 + k); ia.append(ta)
+            tb = b.forward_argmax(tb, k); ib.append(tb)
+        assert ia == solo_a and ib == solo_b
+        with q3.TransformerBuilder(pa).build() as a2:      # a third engine on the same checkpoint
+            assert a2.generate_greedy(5, 2, 20) == solo_a
+
+
 def test_engine_error_behaviour(q3, tmp_ckpt_dir):
     """Same failure surface as TransformerBuilder::build / forward in the reference."""
     with pytest.raises(q3.Q3Error, match="Failed to open checkpoint"):
