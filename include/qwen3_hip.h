@@ -97,6 +97,12 @@ int q3_forward_argmax(q3_engine* e, size_t token, size_t pos, int32_t* next_toke
  * (generation.rs:35) afterwards.  Requires first_pos + n_tokens <= seq_len. */
 int q3_generate_greedy(q3_engine* e, size_t first_token, size_t first_pos, size_t n_tokens, int32_t* out_tokens);
 
+/* The prompt loop of `chat` (handle_user_turn, generation.rs:116-123) kept on the device: every prompt token is
+ * forwarded in order at first_pos, first_pos+1, ... (sequential prefill: identical K/V rows and logits to n calls
+ * of q3_forward), the per-token sample is discarded, and the argmax after the LAST prompt token -- the first
+ * generated token -- is returned.  Continue with q3_generate_greedy(e, *next_token, first_pos + n_tokens, ...). */
+int q3_prefill(q3_engine* e, const int32_t* tokens, size_t n_tokens, size_t first_pos, int32_t* next_token);
+
 /* Fresh-engine state: zero the KV cache (models/qwen3.rs:439-440) */
 int q3_reset_kv(q3_engine* e);
 

@@ -183,6 +183,7 @@ struct q3_engine {
     float *d_tap = nullptr, *d_key = nullptr, *d_value = nullptr, *d_rope = nullptr, *d_att = nullptr;
     State* d_state = nullptr;
     int32_t* d_out_tokens = nullptr;
+    int32_t* d_prompt = nullptr;               // chat-mode prefill: prompt token ids (capacity out_cap)
     int out_cap = 0;
     unsigned long long* d_stamps = nullptr;   // developer timeline (Q3_STAMPS=1)
     unsigned long long* d_argmax_slots = nullptr;
@@ -217,7 +218,7 @@ void launch_one(const Launch& L, q3_engine* e) {
         else hipLaunchKernelGGL(k_attn, dim3(L.grid), dim3(kWG), L.smem, e->stream, L.aa);
     } else if (L.is_next) {
         hipLaunchKernelGGL(k_next, dim3(1), dim3(kWG), 0, e->stream, e->d_state, e->d_argmax_slots, e->n_argmax_slots,
-                           e->d_out_tokens, e->out_cap);
+                           e->d_out_tokens, e->out_cap, e->d_prompt);
     } else {
         hipLaunchKernelGGL(L.fn, dim3(L.grid), dim3(kWG), L.smem, e->stream, L.ga);
     }
@@ -266,7 +267,7 @@ void q3_engine::release() {
     if (graph) (void)hipGraphDestroy(graph);
     if (graph_long_exec) (void)hipGraphExecDestroy(graph_long_exec);
     if (graph_long) (void)hipGraphDestroy(graph_long);
-    void* dptrs[] = {d_att_priv, d_argmax_slots, d_stamps, d_blob, d_x, d_q, d_kraw, d_xb, d_hb, d_logits, d_tap, d_key, d_value, d_rope, d_att, d_state, d_out_tokens};
+    void* dptrs[] = {d_prompt, d_att_priv, d_argmax_slots, d_stamps, d_blob, d_x, d_q, d_kraw, d_xb, d_hb, d_logits, d_tap, d_key, d_value, d_rope, d_att, d_state, d_out_tokens};
     for (void* p : dptrs)
         if (p) (void)hipFree(p);
     if (h_logits) (void)hipHostFree(h_logits);
@@ -406,6 +407,8 @@ int q3_engine::load(const char* path, uint32_t ctx_len) {
     out_cap = (int)S;
     HIP_TRY(hipMalloc((void**)&d_out_tokens, 4 * (size_t)out_cap));
     HIP_TRY(hipMemset(d_out_tokens, 0, 4 * (size_t)out_cap));
+    HIP_TRY(hipMalloc((void**)&d_prompt, 4 * (size_t)out_cap));
+    HIP_TRY(hipMemset(d_prompt, 0, 4 * (size_t)out_cap));
     HIP_TRY(hipHostMalloc((void**)&h_logits, 4 * V, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&h_state, sizeof(State), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&h_tokens, 4 * (size_t)out_cap, hipHostMallocDefault));
@@ -666,7 +669,7 @@ int q3_engine::set_state(size_t token, size_t pos) {
     h_state->token = (int)token;
     h_state->pos = (int)pos;
     h_state->step = 0;
-    h_state->pad = 0;
+    h_state->prompt_len = 0;
     h_state->argmax = 0ull;
     HIP_TRY(hipMemcpyAsync(d_state, h_state, sizeof(State), hipMemcpyHostToDevice, stream));
     return Q3_OK;
@@ -805,6 +808,30 @@ int q3_generate_greedy(q3_engine* e, size_t first_token, size_t first_pos, size_
                 (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3,
                 (t2.tv_sec - t1.tv_sec) * 1e6 + (t2.tv_nsec - t1.tv_nsec) * 1e-3);
     memcpy(out_tokens, e->h_tokens, 4 * n_tokens);
+    return Q3_OK;
+}
+
+int q3_prefill(q3_engine* e, const int32_t* tokens, size_t n_tokens, size_t first_pos, int32_t* next_token) {
+    g_err[0] = 0;
+    if (!e || !tokens || n_tokens == 0) return fail(Q3_ERR_ARG, "null or empty prompt");
+    if (first_pos + n_tokens > (size_t)e->cfg.seq_len)
+        return fail(Q3_ERR_ARG, "first_pos %zu + n_tokens %zu exceeds seq_len %d", first_pos, n_tokens, e->cfg.seq_len);
+    for (size_t i = 0; i < n_tokens; ++i)
+        if (tokens[i] < 0 || tokens[i] >= e->cfg.vocab_size)
+            return fail(Q3_ERR_ARG, "index out of range: token %d (vocab_size %d)", tokens[i], e->cfg.vocab_size);
+    HIP_TRY(hipSetDevice(e->device));
+    memcpy(e->h_tokens, tokens, 4 * n_tokens);
+    HIP_TRY(hipMemcpyAsync(e->d_prompt, e->h_tokens, 4 * n_tokens, hipMemcpyHostToDevice, e->stream));
+    int rc = e->set_state((size_t)tokens[0], first_pos);
+    if (rc) return rc;
+    // set_state queued {token, pos, step 0, prompt_len 0}; patch prompt_len before anything runs
+    e->h_state->prompt_len = (int)n_tokens;
+    HIP_TRY(hipMemcpyAsync(e->d_state, e->h_state, sizeof(State), hipMemcpyHostToDevice, e->stream));
+    for (size_t k = 0; k < n_tokens; ++k)
+        if ((rc = e->enqueue_forward(false, first_pos + k))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->h_tokens, e->d_out_tokens + (n_tokens - 1), 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (next_token) *next_token = e->h_tokens[0];
     return Q3_OK;
 }
 

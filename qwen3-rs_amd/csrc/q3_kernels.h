@@ -184,7 +184,7 @@ struct State {
     int token;                      // input token of the current forward
     int pos;                        // position of the current forward
     int step;                       // forwards completed since the host last set the state
-    int pad;
+    int prompt_len;                 // > 0: tokens 1..prompt_len-1 of the prompt buffer are fed next (chat-mode prefill)
     unsigned long long argmax;      // (total_order_key(logit) << 32) | index, max-reduced
 };
 
@@ -1499,7 +1499,7 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
 // Bookkeeping: consume the argmax cell, advance (token, pos, step)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kWG) void k_next(State* st, const unsigned long long* slots, int nslots, int32_t* out_tokens,
-                                              int out_cap) {
+                                              int out_cap, const int32_t* prompt) {
     __shared__ unsigned long long red[kWaves];
     unsigned long long best = 0ull;
     for (int i = threadIdx.x; i < nslots; i += kWG) best = slots[i] > best ? slots[i] : best;
@@ -1514,10 +1514,13 @@ __global__ __launch_bounds__(kWG) void k_next(State* st, const unsigned long lon
     if (threadIdx.x == 0) {
         for (int w = 1; w < kWaves; ++w) best = red[w] > best ? red[w] : best;
         const int idx = (int)(unsigned)(best & 0xffffffffull);
-        if (st->step < out_cap) out_tokens[st->step] = idx;
-        st->token = idx;
+        const int step = st->step;
+        if (step < out_cap) out_tokens[step] = idx;       // the sample is drawn for every forward (generation.rs:120)
+        // chat-mode prefill (generation.rs:116-123): inside the prompt the next input is the next prompt token and
+        // the sample is discarded; afterwards the sample is fed back (generation.rs:143-147)
+        st->token = (step + 1 < st->prompt_len) ? prompt[step + 1] : idx;
         st->pos = st->pos + 1;
-        st->step = st->step + 1;
+        st->step = step + 1;
         st->argmax = best;
     }
 }

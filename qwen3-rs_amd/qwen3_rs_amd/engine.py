@@ -17,7 +17,7 @@ _DIST_DIR = os.path.dirname(_PKG_DIR)
 # every symbol include/qwen3_hip.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = [
     "q3_create", "q3_get_config", "q3_forward", "q3_destroy", "q3_last_error", "q3_forward_argmax",
-    "q3_generate_greedy", "q3_reset_kv", "q3_read_state", "q3_profile", "q3_profile_name", "q3_parse_header",
+    "q3_generate_greedy", "q3_prefill", "q3_reset_kv", "q3_read_state", "q3_profile", "q3_profile_name", "q3_parse_header",
     "q3_abi_version", "q3_op_quantize", "q3_op_dequantize", "q3_op_matmul", "q3_op_rmsnorm", "q3_op_softmax",
     "q3_op_swiglu", "q3_op_expf", "q3_op_attention", "q3_op_argmax",
 ]
@@ -84,6 +84,7 @@ def load_library() -> C.CDLL:
     L.q3_destroy.restype = None
     L.q3_forward_argmax.argtypes = [C.c_void_p, sz, sz, C.POINTER(C.c_int32)]
     L.q3_generate_greedy.argtypes = [C.c_void_p, sz, sz, sz, C.POINTER(C.c_int32)]
+    L.q3_prefill.argtypes = [C.c_void_p, C.POINTER(C.c_int32), sz, sz, C.POINTER(C.c_int32)]
     L.q3_reset_kv.argtypes = [C.c_void_p]
     L.q3_read_state.argtypes = [C.c_void_p, C.c_int, sz, sz, fp]
     L.q3_profile.argtypes = [C.c_void_p, sz, sz, C.c_int, fp, C.POINTER(C.c_int32), C.c_int]
@@ -161,6 +162,16 @@ class Transformer:
             raise IndexError(self._lib.q3_last_error().decode(errors="replace"))
         _check(rc)
         return [int(buf[i]) for i in range(n_tokens)]
+
+    def prefill(self, tokens, first_pos: int = 0) -> int:
+        """chat-mode prompt loop on the device (generation.rs:116-123); returns the first generated token."""
+        arr = (C.c_int32 * len(tokens))(*[int(t) for t in tokens])
+        out = C.c_int32(-1)
+        rc = self._lib.q3_prefill(self._h, arr, len(tokens), first_pos, C.byref(out))
+        if rc == -3:
+            raise IndexError(self._lib.q3_last_error().decode(errors="replace"))
+        _check(rc)
+        return int(out.value)
 
     def reset_kv(self):
         _check(self._lib.q3_reset_kv(self._h))

@@ -282,6 +282,30 @@ def test_long_context_split_attention_vs_oracle(q3, oracle, tmp_ckpt_dir):
             assert np.max(np.abs(a - b)) <= 2e-5
 
 
+def test_device_prefill_matches_chat_pattern(q3, oracle):
+    """q3_prefill == the prompt loop of `chat` (generation.rs:116-123): same KV rows, same first generated token, and
+    decoding from there reproduces the oracle's chat turn."""
+    path = golden_path("tiny-untied.bin")
+    g = np.load(golden_path("tiny-untied.golden.npz"))
+    prompt = [int(v) for v in g["prompt"]]
+    om = oracle.OracleModel(path)
+    want, pos, _ = q3.chat_turn(om, prompt, 0, 10, sample=oracle.sample_argmax)
+    assert want == [int(v) for v in g["chat_tokens"]]
+    with q3.TransformerBuilder(path).build() as t:
+        first = t.prefill(prompt, 0)
+        assert first == want[0]
+        rest = t.generate_greedy(first, len(prompt), 9)
+        assert [first] + rest == want
+        k, v = om.kv_cache()
+        n = len(prompt) + 9
+        kvd = t.get_config().n_kv_heads * t.get_config().head_dim
+        S = t.get_config().seq_len
+        for layer in range(t.get_config().n_layers):
+            assert_biteq(t.read_state("key", layer * S * kvd, n * kvd), k[layer, :n].reshape(-1), f"K layer {layer}")
+        with pytest.raises(IndexError):
+            t.prefill([1, 2, 999999], 0)
+
+
 def test_two_engines_are_independent(q3):
     """Replicas: engines share nothing (own stream, KV cache, scratch, graphs).  Interleaving two engines -- here on one
     device -- gives each exactly the tokens it produces alone."""

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[2]: Qwen3-4B Q8, 2048-token prefill + 512-token decode on one MI355X.
+
+The reference's chat mode forwards every prompt token through Transformer::forward one at a time
+(generation.rs:116-123), so "prefill" is 2048 sequential forwards; q3_prefill keeps that loop on the device and
+q3_generate_greedy continues from the token it returns.  Prints ONE JSON line with both rates.  Not the default
+bench line (bench.py measures configs[1]); this is the measurement SURVEY.md section 8d asks for config 3.
+
+    python tools/bench_chat.py [--shape qwen3-4b] [--prefill 2048] [--decode 512] [--ctx 4096]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "qwen3-rs_amd"))
+
+import qwen3_rs_amd as q3                                    # noqa: E402
+from qwen3_rs_amd import checkpoint as ck                    # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="qwen3-4b")
+    ap.add_argument("--prefill", type=int, default=2048)
+    ap.add_argument("--decode", type=int, default=512)
+    ap.add_argument("--ctx", type=int, default=4096)
+    ap.add_argument("--seed", type=int, default=1235)
+    ap.add_argument("--ckpt-dir", default=os.environ.get("Q3_CKPT_DIR", "/tmp"))
+    a = ap.parse_args()
+
+    shape = ck.SHAPES[a.shape]
+    path = os.path.join(a.ckpt_dir, f"{a.shape}-seed{a.seed}.q3bin")
+    t0 = time.time()
+    ck.ensure_synthetic_checkpoint(path, shape, seed=a.seed)
+    print(f"[bench_chat] checkpoint {path} ready in {time.time() - t0:.1f}s", file=sys.stderr)
+    prompt = ck.iter_prompt_tokens(shape, a.seed, a.prefill)
+
+    with q3.TransformerBuilder(path).with_ctx_length(a.ctx).build() as t:
+        t.prefill(prompt[:8], 0)                              # warm the graphs
+        t.generate_greedy(prompt[0], 8, 4)
+        best = None
+        for _ in range(2):
+            t.reset_kv()
+            t0 = time.perf_counter()
+            first = t.prefill(prompt, 0)
+            t1 = time.perf_counter()
+            toks = t.generate_greedy(first, a.prefill, a.decode)
+            t2 = time.perf_counter()
+            cur = (t1 - t0, t2 - t1, first, toks)
+            if best is None or cur[0] + cur[1] < best[0] + best[1]:
+                best = cur
+        pre_s, dec_s, first, toks = best
+        nbytes = os.path.getsize(path)
+    print(json.dumps({
+        "metric": "chat_prefill_decode_tokens_per_second", "unit": "tok/s", "n_gpus": 1,
+        "prefill_tok_s": round(a.prefill / pre_s, 2), "decode_tok_s": round(a.decode / dec_s, 2),
+        "prefill_ms_per_token": round(1e3 * pre_s / a.prefill, 4), "decode_ms_per_token": round(1e3 * dec_s / a.decode, 4),
+        "decode_hbm_frac_of_8TBps": round(nbytes / (dec_s / a.decode) / 8e12, 4),
+        "dtype": "int8 weights x int8 activations, f32 accumulate (reference order)", "data": "synthetic",
+        "config": {"workload": f"{a.shape} Q8 chat pattern: {a.prefill}-token sequential prefill + {a.decode}-token "
+                               f"greedy decode, ctx {a.ctx}", "checkpoint_bytes": nbytes, "seed": a.seed},
+        "first_token": first, "last_token": toks[-1],
+    }))
+
+
+if __name__ == "__main__":
+    main()
