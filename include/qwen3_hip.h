@@ -122,6 +122,36 @@ int q3_parse_header(const uint8_t* data, size_t len, q3_config* out);
 uint32_t q3_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
+ * 2b. Batched decode: up to 32 independent streams (each its own KV cache, token and position) advance
+ * one token per step while the weights are streamed ONCE per step through the int8 matrix cores.  This
+ * serves N concurrent `generate` loops (generation.rs:9-48), which the reference can only run as N
+ * processes.  Every stream's logits are bit-identical to the same (token, pos) sequence through
+ * q3_forward on a fresh engine.  Stream i of a call always uses KV slot i.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Allocate the batched state: an MFMA-ordered copy of the weights, max_streams (1..32) zero-filled KV caches
+ * of min(ctx_len, engine seq_len) rows (0 = engine seq_len) and scratch.  Needs group_size 64/128/256 and
+ * every matrix height a multiple of 16 (Q3_ERR_UNSUPPORTED otherwise).  Calling it again re-allocates
+ * (and clears) the state. */
+int q3_batch_init(q3_engine* e, int max_streams, uint32_t ctx_len);
+
+/* One step: stream i runs forward(tokens[i], pos[i]).  logits_out ([n_streams][vocab_size], host) and
+ * argmax_out ([n_streams], sample_argmax of each row, sampler.rs:57-59) may each be NULL. */
+int q3_forward_batch(q3_engine* e, const int32_t* tokens, const int32_t* pos, int n_streams, float* logits_out,
+                     int32_t* argmax_out);
+
+/* n_steps greedy steps for every stream with no host round trip; out_tokens is [n_streams][n_steps]: row i
+ * equals q3_generate_greedy(first_tokens[i], first_pos[i], n_steps) on a fresh engine. */
+int q3_generate_greedy_batch(q3_engine* e, const int32_t* first_tokens, const int32_t* first_pos, int n_streams,
+                             size_t n_steps, int32_t* out_tokens);
+
+/* Zero every stream's KV cache. */
+int q3_batch_reset_kv(q3_engine* e);
+
+/* Parity tap: kind 0 key cache / 1 value cache ([n_layers][ctx][kv_dim]) / 2 residual stream x of one stream. */
+int q3_batch_read_state(q3_engine* e, int stream, int kind, size_t offset, size_t count, float* out);
+
+/* ------------------------------------------------------------------------------------------------
  * 3. Operator-level entry points: the reference's public free functions (tensor.rs, layers.rs) run on
  *    the device over caller (host) buffers.  Used by the parity tests; same kernels/device functions
  *    as the fused forward.  `device` as in q3_create; flags: 0 (reference order) or Q3_FLAG_FAST.

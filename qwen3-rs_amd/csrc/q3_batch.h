@@ -1,0 +1,354 @@
+// Batched decode (BASELINE configs[3]: B <= 32 independent streams advance one token per step).
+//
+// The weights are read ONCE per step for all streams: the W8A8 group-quant matmul of tensor.rs:23-62 becomes a
+// [rows x K] x [K x B] product on the int8 matrix cores.  One v_mfma_i32_16x16x64_i8 produces the exact i32 dots of
+// 16 weight rows x 16 streams over 64 contraction bytes; a quantization group (G = 64 * NJ bytes) is NJ chained
+// MFMAs.  Lane l then owns rows 4*(l/16)+i (i = 0..3) of stream l%16 and folds their per-group f32 terms
+// ((f32)idot * ws) * xs itself, g ascending, starting from -0.0 -- the same operations in the same order as the
+// single-stream GEMV (and the reference), so every stream's logits are bit-identical to its single-stream run.
+//
+// Memory layout (HBM, 288 GB: a second, MFMA-ordered copy of the weights is cheap).  A row tile = 16 consecutive
+// weight rows.  Packed int8: [tile][g][j < NJ][lane 0..63][16 B] where lane (r = l%16, q = l/16) holds bytes
+// [g*G + (q*NJ + j)*16, +16) of row r -- a wave's dwordx4 load is 1 KiB contiguous and a tile is one sequential
+// 16*K-byte stream.  Packed scales: [tile][g][16 rows] f32.  The quantized activations of the step use the same
+// order with streams in place of rows: [stream tile][g][j][lane][16 B] and [stream tile][g][16 streams].
+#pragma once
+#include "q3_kernels.h"
+
+// developer ablation of the batched matmul, compile-time only (-DQ3_BABLATE=bits): 1 no B loads, 2 no scale loads,
+// 4 no math, 8 no A loads.  Runtime switches would make the loads conditional and change what is being measured.
+#ifdef Q3_BABLATE
+#define Q3_BABL(bit) ((Q3_BABLATE & (bit)) != 0)
+#else
+#define Q3_BABL(bit) false
+#endif
+
+namespace q3 {
+
+constexpr int kMaxStreams = 32;
+
+// ------------------------------------------------------------------------------------------------
+// One-time repack of a [rows][n] int8 matrix (+ [rows][n/G] scales) into row-tile order.
+// Destination tile of source tile t is tile0 + t * tile_stride (q|k|v concatenated; w1/w3 interleaved).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWG) void k_pack_weights(const int8_t* __restrict__ wq, const float* __restrict__ ws,
+                                                      int8_t* __restrict__ pq, float* __restrict__ ps, int rows, int n,
+                                                      int G, int tile0, int tile_stride) {
+    const int ng = n / G, nj = G >> 6;
+    const size_t pieces = (size_t)rows * (size_t)(n >> 4);
+    for (size_t p = (size_t)blockIdx.x * kWG + threadIdx.x; p < pieces; p += (size_t)gridDim.x * kWG) {
+        // destination-major enumeration: p = ((t*ng + g)*nj + j)*64 + lane
+        const int lane = (int)(p & 63);
+        size_t rest = p >> 6;
+        const int j = (int)(rest % nj);
+        rest /= nj;
+        const int g = (int)(rest % ng);
+        const size_t t = rest / ng;
+        const int r = lane & 15, q = lane >> 4;
+        const size_t src = (t * 16 + r) * (size_t)n + (size_t)g * G + (size_t)(q * nj + j) * 16;
+        const size_t dt = (size_t)tile0 + t * (size_t)tile_stride;
+        const size_t dst = (((dt * ng + g) * nj + j) * 64 + lane) * 16;
+        *(v4i*)(pq + dst) = *(const v4i*)(wq + src);
+    }
+    const size_t nsc = (size_t)rows * ng;
+    for (size_t p = (size_t)blockIdx.x * kWG + threadIdx.x; p < nsc; p += (size_t)gridDim.x * kWG) {
+        const int r = (int)(p & 15);
+        size_t rest = p >> 4;
+        const int g = (int)(rest % ng);
+        const size_t t = rest / ng;
+        const size_t dt = (size_t)tile0 + t * (size_t)tile_stride;
+        ps[(dt * ng + g) * 16 + r] = ws[(t * 16 + r) * (size_t)ng + g];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-stream activation prologue: exactly the GEMV prologue (embedding / RMSNorm / quantize, same code), one
+// workgroup per stream, result written in the packed MFMA operand order.
+// ------------------------------------------------------------------------------------------------
+struct BQuantArgs {
+    long long in_stride;     // floats between consecutive streams of GemvArgs::in
+    long long x_out_stride;  // PRO_EMBED_NORM: floats between streams of x_out
+    int8_t* xq_p;            // packed int8 activations
+    float* xs_p;             // packed activation scales
+    int n_streams;
+};
+
+template <int PRO>
+__global__ __launch_bounds__(kWG) void k_bquant(const GemvArgs a0, const BQuantArgs b) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr bool kStage = (PRO == PRO_NORM || PRO == PRO_EMBED_NORM);
+    const int sidx = blockIdx.y;                 // blockIdx.x == 0: the prologue's "workgroup 0" side outputs are per stream
+    GemvArgs a = a0;
+    a.in = a0.in ? a0.in + (size_t)sidx * b.in_stride : nullptr;
+    a.st = a0.st + sidx;
+    a.x_out = a0.x_out ? a0.x_out + (size_t)sidx * b.x_out_stride : nullptr;
+    a.tap_out = nullptr;
+    const GemvSmem sm = gemv_carve(smem_raw, a.n, a.group, 1, kStage);
+    ProRegs<PRO> pr;
+    gemv_prologue_issue<PRO>(a, pr);
+    gemv_prologue_finish<PRO, 0>(a, sm, pr);     // ends with __syncthreads(): sm.xq / sm.xs complete
+    const int n = a.n, G = a.group, ng = n / G, nj = G >> 6;
+    const int nt = sidx >> 4, s = sidx & 15;
+    for (int p = threadIdx.x; p < (n >> 4); p += kWG) {
+        const int k0 = p << 4;
+        const int g = k0 / G, within = (k0 % G) >> 4;      // 16-byte piece index inside the group: q*nj + j
+        const int q = within / nj, j = within % nj;
+        const size_t dst = ((((size_t)nt * ng + g) * nj + j) * 64 + (q * 16 + s)) * 16;
+        *(v4i*)(b.xq_p + dst) = ((const v4i*)sm.xq)[p];
+    }
+    for (int g = threadIdx.x; g < ng; g += kWG) b.xs_p[((size_t)nt * ng + g) * 16 + s] = sm.xs[g];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched W8A8 matmul on the matrix cores.
+// ------------------------------------------------------------------------------------------------
+struct BGemmArgs {
+    const int8_t* wq;        // packed row tiles
+    const float* ws;         // packed row-tile scales
+    const int8_t* xq;        // packed activations of this step
+    const float* xs;
+    int ng;                  // groups per row
+    int ntiles;              // row tiles in the packed matrix (SwiGLU: w1 and w3 tiles interleaved)
+    int n_streams;
+    float* out0;             // [stream][rows] destination (RESID: residual stream x; LOGITS: logits or nullptr)
+    long long out0_stride;
+    float* out1;             // QKV: k_raw [stream][kv_dim]
+    long long out1_stride;
+    float* out2;             // QKV: value cache of this layer, stream stride out2_stride, row st[b].pos
+    long long out2_stride;
+    int rows0, rows1;        // QKV: q rows, k rows
+    int pos_stride;          // QKV: floats per cache row (kv_dim)
+    const State* st;         // [stream]
+    unsigned long long* slots;   // LOGITS: [stream][nslots] argmax keys, one per wave of the launch
+    int nslots;
+};
+
+// One workgroup (8 waves) per row task (RT row tiles of 16 rows), the contraction walked in phases of PG groups:
+//   1. the 8 waves split the phase's groups; each wave issues ALL of its A/B fragment loads at once (a phase of a
+//      16-row tile is 64 KiB of weights in flight per CU), runs its MFMAs and writes the f32 group terms
+//      ((f32)idot * ws) * xs to LDS  [term tile: PG groups x 32 streams x 16 rows];
+//   2. after a barrier each of the 512 threads owns one (stream, row) accumulator and folds that accumulator's PG
+//      terms in ascending group order (the strict chain of tensor.rs:53-60, 9 cycles per add), while the next
+//      phase's fragments are already in flight.
+// The contraction is therefore parallel over K even though every accumulator is summed strictly in order, and a
+// 256-tile matrix (4096 rows) still fills all 256 CUs with 8 waves each.
+constexpr int kBW = 8;                        // waves per workgroup
+constexpr int kBThreads = kBW * 64;
+template <int RT> struct BPhase { static constexpr int PG = (RT == 1) ? 32 : 16; };   // 64 KiB term tile: two workgroups per CU
+                                                                                      // (one folds while the other runs its MFMAs)
+__host__ __device__ inline size_t bgemm_smem_bytes(int RT, int NT) {
+    const int PG = RT == 1 ? 32 : 16;
+    return 4 * ((size_t)RT * PG * NT * 256 + (size_t)RT * PG * 16 + (size_t)NT * PG * 16);
+}
+
+template <int EPI, int RT, int NT, int NJ>
+__global__ __launch_bounds__(kBThreads) void k_bgemm(const BGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int PG = BPhase<RT>::PG;        // groups per phase
+    constexpr int GW = PG / kBW;              // groups per wave per phase
+    float* terms = (float*)smem_raw;                          // [RT][PG][NT*16 streams][16 rows]
+    float* wsl = terms + (size_t)RT * PG * NT * 256;          // [RT][PG][16 rows]
+    float* xsl = wsl + RT * PG * 16;                          // [NT][PG][16 streams]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, s = lane & 15;
+    const int ng = a.ng;
+    const int nph = (ng + PG - 1) / PG;
+    const int ntasks = a.ntiles / RT;
+    const size_t tile_v4 = (size_t)ng * NJ * 64;              // v4i per packed tile (weights or activations)
+    const bool fold_thread = tid < NT * 256;                  // (stream, row) accumulator owner
+    const int f_stream = tid >> 4, f_row = tid & 15;
+    unsigned long long best = 0ull;                           // EPI_LOGITS: running argmax key of f_stream (lanes with f_row == 0)
+
+    struct Frag {
+        v4i a[RT][GW][NJ], b[NT][GW][NJ];
+        v4f ws, xs;
+    };
+    auto issue = [&](Frag& F, int task, int p) {
+        // scale chunks first (oldest loads: their LDS write comes first), then the fragments
+        const int g0 = p * PG;
+        if (tid < RT * PG * 4) {
+            const int rt = tid / (PG * 4), i = tid - rt * (PG * 4);
+            const int gi = min(g0 * 4 + i, ng * 4 - 1);
+            F.ws = ((const v4f*)a.ws)[((size_t)(task * RT + rt) * ng) * 4 + gi];
+        }
+        if (tid < NT * PG * 4) {
+            const int nt = tid / (PG * 4), i = tid - nt * (PG * 4);
+            const int gi = min(g0 * 4 + i, ng * 4 - 1);
+            F.xs = ((const v4f*)a.xs)[((size_t)nt * ng) * 4 + gi];
+        }
+#pragma unroll
+        for (int k = 0; k < GW; ++k) {
+            const int g = min(g0 + wave * GW + k, ng - 1);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    F.a[rt][k][j] = Q3_BABL(8) ? (v4i){lane, g, rt, j}
+                                               : __builtin_nontemporal_load((const v4i*)a.wq + (size_t)(task * RT + rt) * tile_v4 + ((size_t)g * NJ + j) * 64 + lane);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    F.b[nt][k][j] = Q3_BABL(1) ? (v4i){lane, g, nt, j} : ((const v4i*)a.xq)[(size_t)nt * tile_v4 + ((size_t)g * NJ + j) * 64 + lane];
+        }
+    };
+    auto commit_scales = [&](const Frag& F) {
+        if (tid < RT * PG * 4) ((v4f*)wsl)[tid] = F.ws;
+        if (tid < NT * PG * 4) ((v4f*)xsl)[tid] = F.xs;
+    };
+
+    float acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = -0.0f;                  // Iterator::sum::<f32>() starts from -0.0
+    // one phase: `cur` holds this phase's fragments (its scale chunks are already in LDS); `nxt` (the same registers)
+    // receives the following phase's as soon as the MFMAs have consumed them
+    auto phase = [&](Frag& cur, Frag& nxt, int task, int p) -> bool {
+        int ntask = task, np = p + 1;
+        if (np == nph) { np = 0; ntask = task + (int)gridDim.x; }
+        const bool more = ntask < ntasks;
+        const int g0 = p * PG;
+        // ---- MFMA: this wave's GW groups of the phase -> f32 terms in LDS
+#pragma unroll
+        for (int k = 0; k < GW; ++k) {
+            const int gg = wave * GW + k;
+            if (g0 + gg < ng) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const v4f wsv = *(const v4f*)(wsl + (rt * PG + gg) * 16 + 4 * q);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        v4i c = {0, 0, 0, 0};
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            c = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.a[rt][k][j], cur.b[nt][k][j], c, 0, 0, 0);
+                        const float xsc = xsl[(nt * PG + gg) * 16 + s];
+                        v4f t;
+                        t.x = (float)c.x * wsv.x; t.x = t.x * xsc;      // tensor.rs:59  ((dot as f32) * ws) * xs
+                        t.y = (float)c.y * wsv.y; t.y = t.y * xsc;
+                        t.z = (float)c.z * wsv.z; t.z = t.z * xsc;
+                        t.w = (float)c.w * wsv.w; t.w = t.w * xsc;
+                        *(v4f*)(terms + ((size_t)(rt * PG + gg) * NT * 16 + nt * 16 + s) * 16 + 4 * q) = t;
+                    }
+                }
+            }
+        }
+        // ---- the fragment registers are free again: request the next phase (or the next task's first phase); it is
+        // in flight during the barriers and the fold.  (A second register set that issues one phase earlier was
+        // measured: no gain -- the phase is bound by its own MFMA -> term -> fold chain, not by load latency.)
+        if (more) issue(nxt, ntask, np);
+        __syncthreads();                                           // terms of this phase complete
+        // ---- fold: one (stream, row) accumulator per thread, ascending groups
+        const int cnt = min(PG, ng - g0);
+        if (fold_thread) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float* tp = terms + (size_t)rt * PG * NT * 256 + tid;
+                float sacc = acc[rt];
+                int gg = 0;
+                for (; gg + 8 <= cnt; gg += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = tp[(size_t)(gg + u) * NT * 256];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sacc = sacc + v[u];
+                }
+                for (; gg < cnt; ++gg) sacc = sacc + tp[(size_t)gg * NT * 256];
+                acc[rt] = sacc;
+            }
+        }
+        if (more) commit_scales(nxt);                              // scale chunks are only read by the MFMA stage
+        __syncthreads();                                           // terms consumed, next scales visible
+
+        if (p == nph - 1) {
+            // ---- epilogue: thread (f_stream, f_row) owns out[f_stream][r0 + f_row] of each of the task's RT tiles
+            if (fold_thread && f_stream < a.n_streams) {
+                const int sb = f_stream;
+                if (EPI == EPI_SWIGLU) {
+                    // packed tiles alternate w1 | w3 of the same 16 hidden units (RT == 2)   layers.rs:468-475
+                    const float g1 = acc[0], u = acc[RT - 1];
+                    const float den = 1.0f + q3_expf(-g1);
+                    const float sw = g1 * (1.0f / den);
+                    a.out0[(size_t)sb * a.out0_stride + (size_t)task * 16 + f_row] = sw * u;
+                } else {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const int r0 = (task * RT + rt) * 16;
+                        const float o = acc[rt];
+                        if (EPI == EPI_QKV) {
+                            float* dst;
+                            if (r0 < a.rows0) dst = a.out0 + (size_t)sb * a.out0_stride + r0;
+                            else if (r0 < a.rows0 + a.rows1) dst = a.out1 + (size_t)sb * a.out1_stride + (r0 - a.rows0);
+                            else dst = a.out2 + (size_t)sb * a.out2_stride + (size_t)a.st[sb].pos * a.pos_stride + (r0 - a.rows0 - a.rows1);
+                            dst[f_row] = o;
+                        } else if (EPI == EPI_RESID) {
+                            float* dst = a.out0 + (size_t)sb * a.out0_stride + r0 + f_row;
+                            *dst = *dst + o;                                   // layers.rs:249-259
+                        } else if (EPI == EPI_LOGITS) {
+                            if (a.out0 != nullptr) a.out0[(size_t)sb * a.out0_stride + r0 + f_row] = o;
+                            const unsigned long long key = ((unsigned long long)total_order_key(o) << 32) | (unsigned)(r0 + f_row);
+                            best = key > best ? key : best;
+                        } else {
+                            a.out0[(size_t)sb * a.out0_stride + r0 + f_row] = o;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = -0.0f;
+        }
+        return more;
+    };
+
+    int task = blockIdx.x, p = 0;
+    if (task < ntasks) {
+        Frag F0;
+        issue(F0, task, 0);
+        commit_scales(F0);
+        __syncthreads();
+        while (phase(F0, F0, task, p))
+            if (++p == nph) { p = 0; task += gridDim.x; }
+    }
+    if (EPI == EPI_LOGITS) {
+        // sampler.rs:57-59 (last maximum): max over the 16 row lanes of each stream, one slot per workgroup
+        for (int m = 1; m < 16; m <<= 1) {
+            const unsigned lo = __shfl_xor((unsigned)best, m);
+            const unsigned hi = __shfl_xor((unsigned)(best >> 32), m);
+            const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+            best = o > best ? o : best;
+        }
+        if (fold_thread && f_row == 0 && f_stream < a.n_streams) a.slots[(size_t)f_stream * a.nslots + blockIdx.x] = best;
+    }
+}
+
+// per-stream k_next: grid = streams
+__global__ __launch_bounds__(kWG) void k_next_batch(State* st, const unsigned long long* slots, int slot_stride, int nslots,
+                                                    int32_t* out_tokens, int out_cap) {
+    __shared__ unsigned long long red[kWaves];
+    const int sb = blockIdx.x;
+    st += sb;
+    slots += (size_t)sb * slot_stride;
+    out_tokens += (size_t)sb * out_cap;
+    unsigned long long best = 0ull;
+    for (int i = threadIdx.x; i < nslots; i += kWG) best = slots[i] > best ? slots[i] : best;
+    for (int m = 1; m < 64; m <<= 1) {
+        const unsigned lo = __shfl_xor((unsigned)best, m);
+        const unsigned hi = __shfl_xor((unsigned)(best >> 32), m);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        best = o > best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kWaves; ++w) best = red[w] > best ? red[w] : best;
+        const int idx = (int)(unsigned)(best & 0xffffffffull);
+        const int step = st->step;
+        if (step < out_cap) out_tokens[step] = idx;
+        st->token = idx;                                   // generation.rs:143-147
+        st->pos = st->pos + 1;
+        st->step = step + 1;
+        st->argmax = best;
+    }
+}
+
+}  // namespace q3

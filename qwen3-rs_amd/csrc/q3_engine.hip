@@ -26,6 +26,7 @@
 
 #include "../../include/qwen3_hip.h"
 #include "q3_kernels.h"
+#include "q3_batch.h"
 
 namespace {
 
@@ -167,6 +168,10 @@ int env_int(const char* name, int dflt) {
 
 }  // namespace
 
+struct BatchCtx;
+struct q3_engine;
+namespace { void batch_free(q3_engine* e); }
+
 struct q3_engine {
     q3_config cfg{};
     uint32_t flags = 0;
@@ -200,6 +205,8 @@ struct q3_engine {
     float* d_att_priv = nullptr;
     int att_stride = 0;
     int split_pos = 256;
+    size_t attn_smem_max = 0;                  // largest dynamic LDS size any k_attn launch of this engine needs
+    BatchCtx* batch = nullptr;                 // batched decode state (q3_batch_init), see q3_batch_host.inc
 
     int load(const char* path, uint32_t ctx_len);
     int build_plan();
@@ -263,6 +270,7 @@ GemvShape plan_gemv(int units, int n, int G, bool swiglu, int row_align, int n_c
 }  // namespace
 
 void q3_engine::release() {
+    batch_free(this);
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (graph) (void)hipGraphDestroy(graph);
     if (graph_long_exec) (void)hipGraphExecDestroy(graph_long_exec);
@@ -526,6 +534,7 @@ int q3_engine::build_plan() {
             Ln.aa = a;
             Ln.grid = (unsigned)cfg.n_heads;
             Ln.smem = attn_smem_bytes(hd, use_att_global ? 0 : S);
+            attn_smem_max = Ln.smem;
             if ((rc = set_max_smem((const void*)k_attn, Ln.smem))) return rc;
             plan.push_back(Ln);
         }
@@ -1196,3 +1205,5 @@ int q3_op_argmax(const float* logits, size_t n, int32_t* index, int device) {
 }
 
 }  // extern "C"
+
+#include "q3_batch_host.inc"

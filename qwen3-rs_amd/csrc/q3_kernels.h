@@ -941,6 +941,9 @@ struct AttnArgs {
     int att_stride;           // floats per score row (>= seq_len rounded up to 256)
     int debug;                // ablation: 8 = return right after the q/k norm+rope
     unsigned long long* stamps;   // developer timeline (block 0, thread 0)
+    // batched decode: blockIdx.y = stream; float strides between streams (all 0 for the single-stream engine)
+    long long sb_q, sb_kraw, sb_kv, sb_xb, sb_att;
+    int tch;                  // K/V timesteps staged per LDS round (0 = attn_tch(hd))
 };
 
 // LDS plan of k_attn (floats): q_s[hd] k_s[hd] raw[2hd] sq[2hd] opart[kWaves*hd] red[64] att[att_lds]
@@ -949,8 +952,8 @@ struct AttnArgs {
 // per-timestep readers hit distinct banks); chunk 0 of both is requested at kernel entry, before q exists.
 constexpr int kKPad = 4;
 __host__ __device__ inline int attn_tch(int hd) { return hd <= 128 ? 128 : 16384 / hd; }
-__host__ __device__ inline size_t attn_smem_bytes(int hd, int att_lds_floats) {
-    const int tch = attn_tch(hd);
+__host__ __device__ inline size_t attn_smem_bytes(int hd, int att_lds_floats, int tch_override = 0) {
+    const int tch = tch_override > 0 ? tch_override : attn_tch(hd);
     return 4 * ((size_t)hd * (6 + kWaves) + 64 + (size_t)((att_lds_floats + 3) & ~3) + (size_t)tch * (2 * hd + kKPad));
 }
 
@@ -1036,11 +1039,22 @@ __device__ __forceinline__ void stage_commit(const StageRegs& sr, float* lds, in
 #else
 #define ATT_STAMP(i) do { } while (0)
 #endif
-__global__ __launch_bounds__(kWG) void k_attn(const AttnArgs a) {
+__global__ __launch_bounds__(kWG) void k_attn(const AttnArgs a0) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    AttnArgs a = a0;
+    {   // batched decode: one grid row per stream, each with its own state, scratch rows and KV cache
+        const size_t sb = blockIdx.y;
+        a.q = a0.q + sb * a0.sb_q;
+        a.k_raw = a0.k_raw + sb * a0.sb_kraw;
+        a.key_cache = a0.key_cache + sb * a0.sb_kv;
+        a.value_cache = a0.value_cache + sb * a0.sb_kv;
+        a.xb = a0.xb + sb * a0.sb_xb;
+        if (a0.att_global) a.att_global = a0.att_global + sb * a0.sb_att;
+        a.st = a0.st + sb;
+    }
     ATT_STAMP(0);
     const int hd = a.hd;
-    const int tch = attn_tch(hd);
+    const int tch = a.tch > 0 ? a.tch : attn_tch(hd);
     const int kld = hd + kKPad;
     float* q_s = (float*)smem_raw;
     float* k_s = q_s + hd;

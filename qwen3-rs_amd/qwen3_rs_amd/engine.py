@@ -17,7 +17,8 @@ _DIST_DIR = os.path.dirname(_PKG_DIR)
 # every symbol include/qwen3_hip.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = [
     "q3_create", "q3_get_config", "q3_forward", "q3_destroy", "q3_last_error", "q3_forward_argmax",
-    "q3_generate_greedy", "q3_prefill", "q3_reset_kv", "q3_read_state", "q3_profile", "q3_profile_name", "q3_parse_header",
+    "q3_generate_greedy", "q3_prefill", "q3_reset_kv", "q3_read_state", "q3_batch_init", "q3_forward_batch",
+    "q3_generate_greedy_batch", "q3_batch_reset_kv", "q3_batch_read_state", "q3_profile", "q3_profile_name", "q3_parse_header",
     "q3_abi_version", "q3_op_quantize", "q3_op_dequantize", "q3_op_matmul", "q3_op_rmsnorm", "q3_op_softmax",
     "q3_op_swiglu", "q3_op_expf", "q3_op_attention", "q3_op_argmax",
 ]
@@ -87,6 +88,12 @@ def load_library() -> C.CDLL:
     L.q3_prefill.argtypes = [C.c_void_p, C.POINTER(C.c_int32), sz, sz, C.POINTER(C.c_int32)]
     L.q3_reset_kv.argtypes = [C.c_void_p]
     L.q3_read_state.argtypes = [C.c_void_p, C.c_int, sz, sz, fp]
+    i32p = C.POINTER(C.c_int32)
+    L.q3_batch_init.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+    L.q3_forward_batch.argtypes = [C.c_void_p, i32p, i32p, C.c_int, fp, i32p]
+    L.q3_generate_greedy_batch.argtypes = [C.c_void_p, i32p, i32p, C.c_int, sz, i32p]
+    L.q3_batch_reset_kv.argtypes = [C.c_void_p]
+    L.q3_batch_read_state.argtypes = [C.c_void_p, C.c_int, C.c_int, sz, sz, fp]
     L.q3_profile.argtypes = [C.c_void_p, sz, sz, C.c_int, fp, C.POINTER(C.c_int32), C.c_int]
     L.q3_profile_name.argtypes = [C.c_int]
     L.q3_profile_name.restype = C.c_char_p
@@ -183,6 +190,48 @@ class Transformer:
         count = total - offset if count is None else count
         out = np.zeros(count, dtype=np.float32)
         _check(self._lib.q3_read_state(self._h, kinds[kind], offset, count, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    # ---- batched decode (include/qwen3_hip.h section 2b): N concurrent generate loops, weights streamed once per step
+    def batch_init(self, max_streams: int, ctx_len: int = 0):
+        _check(self._lib.q3_batch_init(self._h, max_streams, ctx_len))
+        self._batch_ctx = min(ctx_len, self._config.seq_len) if ctx_len else self._config.seq_len
+
+    def _batch_rc(self, rc):
+        if rc == -3:
+            raise IndexError(self._lib.q3_last_error().decode(errors="replace"))
+        _check(rc)
+
+    def forward_batch(self, tokens, pos, want_logits: bool = True):
+        """Stream i runs forward(tokens[i], pos[i]); returns (logits [n, vocab] or None, argmax list)."""
+        n = len(tokens)
+        tk = (C.c_int32 * n)(*[int(t) for t in tokens])
+        ps = (C.c_int32 * n)(*[int(p) for p in pos])
+        am = (C.c_int32 * n)()
+        logits = np.zeros((n, self._config.vocab_size), dtype=np.float32) if want_logits else None
+        lp = logits.ctypes.data_as(C.POINTER(C.c_float)) if want_logits else None
+        self._batch_rc(self._lib.q3_forward_batch(self._h, tk, ps, n, lp, am))
+        return logits, [int(v) for v in am]
+
+    def generate_greedy_batch(self, first_tokens, first_pos, n_steps: int) -> np.ndarray:
+        """[n_streams, n_steps] greedy tokens, the whole loop on the device."""
+        n = len(first_tokens)
+        tk = (C.c_int32 * n)(*[int(t) for t in first_tokens])
+        ps = (C.c_int32 * n)(*[int(p) for p in first_pos])
+        out = np.zeros((n, n_steps), dtype=np.int32)
+        self._batch_rc(self._lib.q3_generate_greedy_batch(self._h, tk, ps, n, n_steps, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
+    def batch_reset_kv(self):
+        _check(self._lib.q3_batch_reset_kv(self._h))
+
+    def batch_read_state(self, stream: int, kind: str, offset: int = 0, count: Optional[int] = None) -> np.ndarray:
+        c = self._config
+        kinds = {"key": 0, "value": 1, "x": 2}
+        total = c.dim if kind == "x" else c.n_layers * self._batch_ctx * c.n_kv_heads * c.head_dim
+        count = total - offset if count is None else count
+        out = np.zeros(count, dtype=np.float32)
+        _check(self._lib.q3_batch_read_state(self._h, stream, kinds[kind], offset, count, out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
     def profile(self, token: int, pos: int, reps: int = 1):
