@@ -23,6 +23,12 @@
 #define Q3_BABL(bit) false
 #endif
 
+#ifdef Q3_DEV
+#define BG_STAMP(i) do { if (a.stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && sidx < 12) a.stamps[sidx * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BG_STAMP(i) do { } while (0)
+#endif
+
 namespace q3 {
 
 constexpr int kMaxStreams = 32;
@@ -119,6 +125,7 @@ struct BGemmArgs {
     int rows0, rows1;        // QKV: q rows, k rows
     int pos_stride;          // QKV: floats per cache row (kv_dim)
     const State* st;         // [stream]
+    unsigned long long* stamps;  // developer timeline (Q3_DEV builds, block 0 thread 0): 5 stamps per phase
     unsigned long long* slots;   // LOGITS: [stream][nslots] argmax keys, one per wave of the launch
     int nslots;
 };
@@ -164,8 +171,7 @@ __global__ __launch_bounds__(kBThreads) void k_bgemm(const BGemmArgs a) {
         v4i a[RT][GW][NJ], b[NT][GW][NJ];
         v4f ws, xs;
     };
-    auto issue = [&](Frag& F, int task, int p) {
-        // scale chunks first (oldest loads: their LDS write comes first), then the fragments
+    auto issue_scales = [&](Frag& F, int task, int p) {
         const int g0 = p * PG;
         if (tid < RT * PG * 4) {
             const int rt = tid / (PG * 4), i = tid - rt * (PG * 4);
@@ -177,21 +183,25 @@ __global__ __launch_bounds__(kBThreads) void k_bgemm(const BGemmArgs a) {
             const int gi = min(g0 * 4 + i, ng * 4 - 1);
             F.xs = ((const v4f*)a.xs)[((size_t)nt * ng) * 4 + gi];
         }
+    };
+    auto issue_group = [&](Frag& F, int task, int p, int k) {     // fragments of this wave's k-th group of phase p
+        const int g = min(p * PG + wave * GW + k, ng - 1);
 #pragma unroll
-        for (int k = 0; k < GW; ++k) {
-            const int g = min(g0 + wave * GW + k, ng - 1);
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
+            for (int j = 0; j < NJ; ++j)
+                F.a[rt][k][j] = Q3_BABL(8) ? (v4i){lane, g, rt, j}
+                                           : __builtin_nontemporal_load((const v4i*)a.wq + (size_t)(task * RT + rt) * tile_v4 + ((size_t)g * NJ + j) * 64 + lane);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    F.a[rt][k][j] = Q3_BABL(8) ? (v4i){lane, g, rt, j}
-                                               : __builtin_nontemporal_load((const v4i*)a.wq + (size_t)(task * RT + rt) * tile_v4 + ((size_t)g * NJ + j) * 64 + lane);
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int j = 0; j < NJ; ++j)
+                F.b[nt][k][j] = Q3_BABL(1) ? (v4i){lane, g, nt, j} : ((const v4i*)a.xq)[(size_t)nt * tile_v4 + ((size_t)g * NJ + j) * 64 + lane];
+    };
+    auto issue = [&](Frag& F, int task, int p) {
+        issue_scales(F, task, p);                                 // oldest loads: their LDS write comes first
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    F.b[nt][k][j] = Q3_BABL(1) ? (v4i){lane, g, nt, j} : ((const v4i*)a.xq)[(size_t)nt * tile_v4 + ((size_t)g * NJ + j) * 64 + lane];
-        }
+        for (int k = 0; k < GW; ++k) issue_group(F, task, p, k);
     };
     auto commit_scales = [&](const Frag& F) {
         if (tid < RT * PG * 4) ((v4f*)wsl)[tid] = F.ws;
@@ -199,6 +209,8 @@ __global__ __launch_bounds__(kBThreads) void k_bgemm(const BGemmArgs a) {
     };
 
     float acc[RT];
+    int sidx = 0;      // developer stamps: phases seen by this workgroup
+    (void)sidx;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) acc[rt] = -0.0f;                  // Iterator::sum::<f32>() starts from -0.0
     // one phase: `cur` holds this phase's fragments (its scale chunks are already in LDS); `nxt` (the same registers)
@@ -208,20 +220,33 @@ __global__ __launch_bounds__(kBThreads) void k_bgemm(const BGemmArgs a) {
         if (np == nph) { np = 0; ntask = task + (int)gridDim.x; }
         const bool more = ntask < ntasks;
         const int g0 = p * PG;
-        // ---- MFMA: this wave's GW groups of the phase -> f32 terms in LDS
+        BG_STAMP(0);
+        // ---- MFMA: this wave's GW groups of the phase -> f32 terms in LDS.  Each group's fragment registers are
+        // re-requested for the next phase as soon as its MFMAs have read them: the loads trickle through the CU's
+        // texture path during the math instead of arriving as one burst from all 16 waves after it.
+        if (more) issue_scales(nxt, ntask, np);
 #pragma unroll
         for (int k = 0; k < GW; ++k) {
             const int gg = wave * GW + k;
+            v4i cacc[RT][NT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    v4i c = {0, 0, 0, 0};
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        c = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.a[rt][k][j], cur.b[nt][k][j], c, 0, 0, 0);
+                    cacc[rt][nt] = c;
+                }
+            if (more) issue_group(nxt, ntask, np, k);
             if (g0 + gg < ng) {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
                     const v4f wsv = *(const v4f*)(wsl + (rt * PG + gg) * 16 + 4 * q);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        v4i c = {0, 0, 0, 0};
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j)
-                            c = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.a[rt][k][j], cur.b[nt][k][j], c, 0, 0, 0);
+                        const v4i c = cacc[rt][nt];
                         const float xsc = xsl[(nt * PG + gg) * 16 + s];
                         v4f t;
                         t.x = (float)c.x * wsv.x; t.x = t.x * xsc;      // tensor.rs:59  ((dot as f32) * ws) * xs
@@ -233,11 +258,10 @@ __global__ __launch_bounds__(kBThreads) void k_bgemm(const BGemmArgs a) {
                 }
             }
         }
-        // ---- the fragment registers are free again: request the next phase (or the next task's first phase); it is
-        // in flight during the barriers and the fold.  (A second register set that issues one phase earlier was
-        // measured: no gain -- the phase is bound by its own MFMA -> term -> fold chain, not by load latency.)
-        if (more) issue(nxt, ntask, np);
+        BG_STAMP(1);
+        BG_STAMP(2);
         __syncthreads();                                           // terms of this phase complete
+        BG_STAMP(3);
         // ---- fold: one (stream, row) accumulator per thread, ascending groups
         const int cnt = min(PG, ng - g0);
         if (fold_thread) {
@@ -257,8 +281,12 @@ __global__ __launch_bounds__(kBThreads) void k_bgemm(const BGemmArgs a) {
                 acc[rt] = sacc;
             }
         }
+        BG_STAMP(4);
         if (more) commit_scales(nxt);                              // scale chunks are only read by the MFMA stage
+        BG_STAMP(5);
         __syncthreads();                                           // terms consumed, next scales visible
+        BG_STAMP(6);
+        ++sidx;
 
         if (p == nph - 1) {
             // ---- epilogue: thread (f_stream, f_row) owns out[f_stream][r0 + f_row] of each of the task's RT tiles

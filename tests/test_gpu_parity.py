@@ -306,6 +306,81 @@ def test_device_prefill_matches_chat_pattern(q3, oracle):
             t.prefill([1, 2, 999999], 0)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Batched decode (include/qwen3_hip.h section 2b): every stream bit-identical to its single-stream run
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape_name,n_streams", [("tiny-g64", 3), ("tiny-g64", 32), ("small-hd128", 16), ("small-hd128", 32)])
+def test_batched_decode_is_bit_identical_per_stream(q3, shape_name, n_streams, tmp_path_factory):
+    """q3_forward_batch / q3_generate_greedy_batch: int8 MFMA over all streams, per-stream logits bit-identical to
+    q3_forward on a fresh engine (same (token, pos) sequence), greedy tokens identical, KV rows identical."""
+    ck = q3.checkpoint
+    shape = ck.SHAPES[shape_name]
+    path = str(tmp_path_factory.mktemp("bat") / f"{shape_name}.bin")
+    ck.write_synthetic_checkpoint(path, shape, seed=4321)
+    rng = np.random.default_rng(11)
+    toks0 = [int(t) for t in rng.integers(0, shape.vocab_size, n_streams)]
+    pos0 = [int(p) for p in rng.integers(0, 6, n_streams)]      # ragged start positions, zero KV prefix
+    steps = 5
+    ref_logits, ref_tokens, ref_k = [], [], []
+    for i in range(min(n_streams, 6)):                           # the first streams are checked against single-stream runs
+        with q3.TransformerBuilder(path).build() as t:
+            tok, ll, tt = toks0[i], [], []
+            for k in range(steps):
+                lg = np.array(t.forward(tok, pos0[i] + k), copy=True)
+                ll.append(lg)
+                tok = q3.sample_argmax(lg)
+                tt.append(tok)
+            ref_logits.append(ll)
+            ref_tokens.append(tt)
+            ref_k.append((t.read_state("key"), t.read_state("value")))
+    with q3.TransformerBuilder(path).build() as t:
+        t.batch_init(n_streams)
+        toks = list(toks0)
+        for k in range(steps):
+            lg, am = t.forward_batch(toks, [p + k for p in pos0])
+            for i in range(len(ref_logits)):
+                assert_biteq(lg[i], ref_logits[i][k], f"stream {i} step {k} logits")
+                assert am[i] == ref_tokens[i][k]
+            toks = am
+        for i in range(len(ref_logits)):
+            assert_biteq(t.batch_read_state(i, "key"), ref_k[i][0], f"stream {i} key cache")
+            assert_biteq(t.batch_read_state(i, "value"), ref_k[i][1], f"stream {i} value cache")
+        t.batch_reset_kv()
+        out = t.generate_greedy_batch(toks0, pos0, steps)
+        for i in range(len(ref_tokens)):
+            assert [int(v) for v in out[i]] == ref_tokens[i]
+        # a smaller batch on the same engine re-plans and still matches; the single-stream path is untouched
+        t.batch_reset_kv()
+        out2 = t.generate_greedy_batch(toks0[:2], pos0[:2], steps)
+        assert [int(v) for v in out2[0]] == ref_tokens[0] and [int(v) for v in out2[1]] == ref_tokens[1]
+        lg1 = np.array(t.forward(toks0[0], pos0[0]), copy=True)
+        assert_biteq(lg1, ref_logits[0][0], "single-stream forward after batched use")
+
+
+def test_batched_decode_error_behaviour(q3, tmp_path_factory):
+    ck = q3.checkpoint
+    path = str(tmp_path_factory.mktemp("bat") / "tiny-g64.bin")
+    ck.write_synthetic_checkpoint(path, ck.SHAPES["tiny-g64"], seed=1)
+    with q3.TransformerBuilder(path).build() as t:
+        with pytest.raises(IndexError):
+            t.forward_batch([1], [0])                             # q3_batch_init not called
+        t.batch_init(4)
+        with pytest.raises(IndexError):
+            t.forward_batch([1, 2, 3, 4, 5], [0] * 5)             # more streams than allocated
+        with pytest.raises(IndexError):
+            t.forward_batch([10 ** 6], [0])                       # token out of range, like forward()
+        with pytest.raises(IndexError):
+            t.forward_batch([1], [10 ** 6])
+        with pytest.raises(q3.Q3Error):
+            t.batch_init(33)
+    g16 = str(tmp_path_factory.mktemp("bat") / "tiny.bin")
+    ck.write_synthetic_checkpoint(g16, ck.SHAPES["tiny"], seed=1)   # group 16: below one 64-byte MFMA step
+    with q3.TransformerBuilder(g16).build() as t:
+        with pytest.raises(q3.Q3Error) as ei:
+            t.batch_init(2)
+        assert ei.value.code == -5
+
+
 def test_two_engines_are_independent(q3):
     """Replicas: engines share nothing (own stream, KV cache, scratch, graphs).  Interleaving two engines -- here on one
     device -- gives each exactly the tokens it produces alone."""
