@@ -349,6 +349,202 @@ __global__ __launch_bounds__(kBThreads) void k_bgemm(const BGemmArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Batched attention: one workgroup per (stream, kv head).  Wave w < kv_mul owns query head kvh*kv_mul + w; the
+// extra wave normalises + rotates the key row.  The kv head's K (then V) rows are staged in LDS ONCE for all
+// kv_mul query heads (grouped-query sharing), 32 streams x 8 kv heads = 256 workgroups = one per CU.  Every
+// sum is walked in the reference order (layers.rs:346-419,495-506), so the result is bit-identical to k_attn in
+// reference-order mode; Q3_FLAG_FAST engines use this exact path too (exact is always admissible).
+// ------------------------------------------------------------------------------------------------
+constexpr int kGqaTch = 128;            // timesteps staged per LDS round
+constexpr int kGqaSlots = 16;           // float4 staging registers per thread (tch*hd/4 <= slots * threads)
+__host__ __device__ inline int gqa_att_stride(int seq_len) { return (seq_len + 255) & ~255; }
+__host__ __device__ inline size_t attn_gqa_smem_bytes(int hd, int kv_mul, int seq_len) {
+    const size_t nw = (size_t)kv_mul + 1;
+    return 4 * (nw * hd * 3 + (size_t)kv_mul * gqa_att_stride(seq_len) + (size_t)kGqaTch * (hd + kKPad));
+}
+
+__global__ __launch_bounds__(512) void k_attn_gqa(const AttnArgs a0) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int hd = a0.hd, kv_mul = a0.n_heads / a0.n_kv_heads, nw = kv_mul + 1;
+    const int kvh = blockIdx.x;
+    const size_t sbi = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = nw * 64;
+    const bool kwave = wave == kv_mul;
+    const int h = kvh * kv_mul + (kwave ? 0 : wave);
+    const size_t kvd = (size_t)a0.n_kv_heads * hd;
+    const int ast = gqa_att_stride(a0.seq_len);
+    const int kld = hd + kKPad;
+
+    float* q_s = (float*)smem_raw;                 // [kv_mul][hd] normalised + rotated queries, then k_s[hd]
+    float* k_s = q_s + kv_mul * hd;
+    float* raw = k_s + hd;                         // [nw][hd]
+    float* sq = raw + nw * hd;                     // [nw][hd]
+    float* att_l = sq + nw * hd;                   // [kv_mul][ast] score / probability rows (the host picks this kernel only when they fit)
+    float* buf = att_l + (size_t)kv_mul * ast;     // [tch][hd+4] K rows, later [tch][hd] V rows
+
+    const State* st = a0.st + sbi;
+    const int pos = a0.pos_override >= 0 ? a0.pos_override : st->pos;
+    const int np = pos + 1;
+    const float* qsrc = a0.q + sbi * a0.sb_q + (size_t)h * hd;
+    const float* ksrc = a0.k_raw + sbi * a0.sb_kraw + (size_t)kvh * hd;
+    float* key_cache = a0.key_cache + sbi * a0.sb_kv;
+    const float* kbase = key_cache + (size_t)kvh * hd;
+    const float* vbase = a0.value_cache + sbi * a0.sb_kv + (size_t)kvh * hd;
+    float* att = att_l + (size_t)(kwave ? 0 : wave) * ast;
+    const float* cs = a0.rope + (size_t)pos * hd;
+
+    // ---- raw q heads / raw k row, norm weights and rope pairs; then chunk 0 of K: all in flight together
+    float r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = min(lane + 64 * u, hd - 1);
+        r[u] = kwave ? ksrc[i] : qsrc[i];
+    }
+    RopeRegs rr;
+    rope_regs_load(rr, kwave ? a0.k_norm_w : a0.q_norm_w, cs, hd);
+    const int q4s = __builtin_ctz(hd >> 2);        // float4 per row = 1 << q4s
+    v4f sr[kGqaSlots];
+    auto stage_issue_g = [&](const float* gbase, int t0, int cnt) {
+        const int total = cnt << q4s;
+#pragma unroll
+        for (int u = 0; u < kGqaSlots; ++u) {
+            const int idx = tid + u * nthr;
+            if (u * nthr < total) {                // wave-uniform
+                const int ii = min(idx, total - 1);
+                const int row = ii >> q4s, c = ii & ((1 << q4s) - 1);
+                sr[u] = *(const v4f*)(gbase + (size_t)(t0 + row) * kvd + 4 * c);
+            }
+        }
+    };
+    auto stage_commit_g = [&](int ld, int t0, int cnt, int skip) {
+        const int total = cnt << q4s;
+#pragma unroll
+        for (int u = 0; u < kGqaSlots; ++u) {
+            const int idx = tid + u * nthr;
+            if (idx < total) {
+                const int row = idx >> q4s, c = idx & ((1 << q4s) - 1);
+                if (t0 + row != skip) *(v4f*)(buf + row * ld + 4 * c) = sr[u];
+            }
+        }
+    };
+    const int tch = kGqaTch;
+    const int nch = (np + tch - 1) / tch;
+    stage_issue_g(kbase, 0, min(tch, np));
+
+    float* raw_w = raw + wave * hd;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (lane + 64 * u < hd) raw_w[lane + 64 * u] = r[u];
+    wave_lds_sync();
+    wave_norm_rope(kwave ? k_s : q_s + wave * hd, raw_w, sq + wave * hd, rr, hd, 1);   // layers.rs:346-372
+    __syncthreads();
+    if (kwave) {                                   // K is normalised + rotated in place in the cache
+        float* krow = key_cache + (size_t)pos * kvd + (size_t)kvh * hd;
+        for (int i = lane; i < hd; i += 64) krow[i] = k_s[i];
+    }
+    const float scale = 1.0f / sqrtf((float)hd);   // (head_dim as f32).sqrt().recip()
+
+    // ---- scores: att[t] = (q . K[t]) * scale                                   layers.rs:391-401
+    for (int c = 0; c < nch; ++c) {
+        const int t0 = c * tch, cnt = min(tch, np - t0);
+        stage_commit_g(kld, t0, cnt, pos);
+        if (pos >= t0 && pos < t0 + cnt)           // the current position's K comes from this kernel, not the cache
+            for (int i = tid; i < hd; i += nthr) buf[(pos - t0) * kld + i] = k_s[i];
+        __syncthreads();
+        if (c + 1 < nch) stage_issue_g(kbase, t0 + tch, min(tch, np - t0 - tch));     // next chunk under the dots
+        if (!kwave) {
+            const v4f* q4 = (const v4f*)(q_s + wave * hd);
+            for (int t = lane; t < cnt; t += 64) {
+                const v4f* k4 = (const v4f*)(buf + t * kld);
+                float dot = -0.0f;
+                const int nq = hd >> 2;
+                int i = 0;
+                for (; i + 16 <= nq; i += 16) {
+                    v4f kk[16], qq[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) { kk[u] = k4[i + u]; qq[u] = q4[i + u]; }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        float p = qq[u].x * kk[u].x; dot = dot + p;
+                        p = qq[u].y * kk[u].y; dot = dot + p;
+                        p = qq[u].z * kk[u].z; dot = dot + p;
+                        p = qq[u].w * kk[u].w; dot = dot + p;
+                    }
+                }
+                for (; i < nq; ++i) {
+                    const v4f kv = k4[i], qv = q4[i];
+                    float p = qv.x * kv.x; dot = dot + p;
+                    p = qv.y * kv.y; dot = dot + p;
+                    p = qv.z * kv.z; dot = dot + p;
+                    p = qv.w * kv.w; dot = dot + p;
+                }
+                att[t0 + t] = dot * scale;
+            }
+        }
+        __syncthreads();                           // chunk consumed before the next one lands in buf
+    }
+    stage_issue_g(vbase, 0, min(tch, np));         // V chunk 0 under the softmax
+
+    // ---- softmax, one wave per head                                            layers.rs:495-506
+    if (!kwave) {
+        wave_lds_sync();
+        float m = -__builtin_inff();
+        for (int t = lane; t < np; t += 64) m = fmaxf(m, att[t]);
+        m = group_max_f32(m, 64);
+        const int npad = (np + 255) & ~255;
+        for (int t = lane; t < npad; t += 64) att[t] = (t < np) ? q3_expf(att[t] - m) : 0.0f;   // +0.0 padding: sums unchanged
+        wave_lds_sync();
+        float sum;
+        if (np < 256) {
+            const int nq4 = np >> 2;
+            sum = seq_chain(-0.0f, (const v4f*)att, nq4);
+            for (int t = nq4 << 2; t < np; ++t) sum = sum + att[t];
+        } else {
+            sum = seq_sum_blocks(att, 64, npad >> 6, npad >> 6, nullptr);
+        }
+        const float inv = 1.0f / sum;
+        for (int t = lane; t < np; t += 64) att[t] = att[t] * inv;
+        wave_lds_sync();
+    }
+
+    // ---- xb = sum_t att[t] * V[t]  (fill(0.0) then += in t order)              layers.rs:406-417
+    float o[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int c = 0; c < nch; ++c) {
+        const int t0 = c * tch, cnt = min(tch, np - t0);
+        stage_commit_g(hd, t0, cnt, -1);
+        __syncthreads();
+        if (c + 1 < nch) stage_issue_g(vbase, t0 + tch, min(tch, np - t0 - tch));
+        if (!kwave) {
+            const float* w = att + t0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (lane + 64 * u < hd) {          // wave-uniform for hd % 64 == 0; guarded lanes otherwise
+                    const float* v = buf + lane + 64 * u;
+                    float acc = o[u];
+                    int t = 0;
+                    for (; t + 16 <= cnt; t += 16) {
+                        float vv[16], ww[16];
+#pragma unroll
+                        for (int x = 0; x < 16; ++x) { vv[x] = v[(t + x) * hd]; ww[x] = w[t + x]; }
+#pragma unroll
+                        for (int x = 0; x < 16; ++x) { const float p = ww[x] * vv[x]; acc = acc + p; }
+                    }
+                    for (; t < cnt; ++t) { const float p = w[t] * v[t * hd]; acc = acc + p; }
+                    o[u] = acc;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!kwave) {
+        float* out = a0.xb + sbi * a0.sb_xb + (size_t)h * hd;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (lane + 64 * u < hd) out[lane + 64 * u] = o[u];
+    }
+}
+
 // per-stream k_next: grid = streams
 __global__ __launch_bounds__(kWG) void k_next_batch(State* st, const unsigned long long* slots, int slot_stride, int nslots,
                                                     int32_t* out_tokens, int out_cap) {

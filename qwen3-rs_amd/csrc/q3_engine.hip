@@ -205,7 +205,6 @@ struct q3_engine {
     float* d_att_priv = nullptr;
     int att_stride = 0;
     int split_pos = 256;
-    size_t attn_smem_max = 0;                  // largest dynamic LDS size any k_attn launch of this engine needs
     BatchCtx* batch = nullptr;                 // batched decode state (q3_batch_init), see q3_batch_host.inc
 
     int load(const char* path, uint32_t ctx_len);
@@ -534,7 +533,6 @@ int q3_engine::build_plan() {
             Ln.aa = a;
             Ln.grid = (unsigned)cfg.n_heads;
             Ln.smem = attn_smem_bytes(hd, use_att_global ? 0 : S);
-            attn_smem_max = Ln.smem;
             if ((rc = set_max_smem((const void*)k_attn, Ln.smem))) return rc;
             plan.push_back(Ln);
         }

@@ -1039,19 +1039,23 @@ __device__ __forceinline__ void stage_commit(const StageRegs& sr, float* lds, in
 #else
 #define ATT_STAMP(i) do { } while (0)
 #endif
-__global__ __launch_bounds__(kWG) void k_attn(const AttnArgs a0) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+__device__ __forceinline__ void attn_body(const AttnArgs& a);
+__global__ __launch_bounds__(kWG) void k_attn(const AttnArgs a) { attn_body(a); }
+// batched decode: one grid row per stream, each with its own state, scratch rows and KV cache
+__global__ __launch_bounds__(kWG) void k_attn_streams(const AttnArgs a0) {
     AttnArgs a = a0;
-    {   // batched decode: one grid row per stream, each with its own state, scratch rows and KV cache
-        const size_t sb = blockIdx.y;
-        a.q = a0.q + sb * a0.sb_q;
-        a.k_raw = a0.k_raw + sb * a0.sb_kraw;
-        a.key_cache = a0.key_cache + sb * a0.sb_kv;
-        a.value_cache = a0.value_cache + sb * a0.sb_kv;
-        a.xb = a0.xb + sb * a0.sb_xb;
-        if (a0.att_global) a.att_global = a0.att_global + sb * a0.sb_att;
-        a.st = a0.st + sb;
-    }
+    const size_t sb = blockIdx.y;
+    a.q = a0.q + sb * a0.sb_q;
+    a.k_raw = a0.k_raw + sb * a0.sb_kraw;
+    a.key_cache = a0.key_cache + sb * a0.sb_kv;
+    a.value_cache = a0.value_cache + sb * a0.sb_kv;
+    a.xb = a0.xb + sb * a0.sb_xb;
+    if (a0.att_global) a.att_global = a0.att_global + sb * a0.sb_att;
+    a.st = a0.st + sb;
+    attn_body(a);
+}
+__device__ __forceinline__ void attn_body(const AttnArgs& a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     ATT_STAMP(0);
     const int hd = a.hd;
     const int tch = a.tch > 0 ? a.tch : attn_tch(hd);

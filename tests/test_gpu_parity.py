@@ -357,6 +357,29 @@ def test_batched_decode_is_bit_identical_per_stream(q3, shape_name, n_streams, t
         assert_biteq(lg1, ref_logits[0][0], "single-stream forward after batched use")
 
 
+def test_batched_decode_long_positions(q3, tmp_path_factory):
+    """Positions past 256 (multi-chunk K/V staging, speculative exact softmax sum in the per-kv-head attention kernel):
+    330 greedy steps per stream equal the single-stream run, and so do the logits of one more forward."""
+    ck = q3.checkpoint
+    shape = ck.SHAPES["small-longctx"]
+    path = str(tmp_path_factory.mktemp("bat") / "small-longctx.bin")
+    ck.write_synthetic_checkpoint(path, shape, seed=77)
+    toks0, pos0, steps = [3, 99, 250, 17], [0, 5, 1, 40], 330
+    with q3.TransformerBuilder(path).with_ctx_length(512).build() as t:
+        ref, ref_logits = [], []
+        for i in range(4):
+            t.reset_kv()
+            ref.append(t.generate_greedy(toks0[i], pos0[i], steps))
+            ref_logits.append(np.array(t.forward(ref[i][-1], pos0[i] + steps), copy=True))
+        t.batch_init(4)
+        out = t.generate_greedy_batch(toks0, pos0, steps)
+        for i in range(4):
+            assert [int(v) for v in out[i]] == ref[i], f"stream {i}"
+        lg, _ = t.forward_batch([r[-1] for r in ref], [p + steps for p in pos0])
+        for i in range(4):
+            assert_biteq(lg[i], ref_logits[i], f"stream {i} logits at pos {pos0[i] + steps}")
+
+
 def test_batched_decode_error_behaviour(q3, tmp_path_factory):
     ck = q3.checkpoint
     path = str(tmp_path_factory.mktemp("bat") / "tiny-g64.bin")
