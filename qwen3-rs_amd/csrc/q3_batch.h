@@ -542,6 +542,31 @@ __global__ __launch_bounds__(512) void k_attn_gqa(const AttnArgs a0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (lane + 64 * u < hd) out[lane + 64 * u] = o[u];
+        if (a0.pack_q != nullptr) {
+            // the Wo matmul's activation prologue, fused: quantize this head's hd outputs (hd % G == 0, so its groups
+            // are whole) exactly as tensor.rs:91-119 and store them in the packed operand order of q3_batch.h
+            const int G = a0.group, upg = G >> 6, nj = G >> 6;
+            const int ngx = (a0.n_heads * hd) / G;
+            const int nt = (int)(sbi >> 4), s = (int)(sbi & 15);
+            float mu[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) mu[u] = group_max_f32((lane + 64 * u < hd) ? fabsf(o[u]) : 0.0f, 64);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (lane + 64 * u < hd) {
+                    float m = mu[u];
+                    if (upg >= 2) m = fmaxf(mu[u & ~1], mu[u | 1]);
+                    if (upg >= 4) m = fmaxf(fmaxf(mu[0], mu[1]), fmaxf(mu[2], mu[3]));
+                    const float scale = m / 127.0f;
+                    const int qv = (scale != 0.0f) ? quant_round_i8(o[u] / scale) : 0;
+                    const int k0 = h * hd + 64 * u + lane;
+                    const int g = k0 / G, within = (k0 % G) >> 4;
+                    const int qq = within / nj, j = within % nj;
+                    a0.pack_q[((((size_t)nt * ngx + g) * nj + j) * 64 + (qq * 16 + s)) * 16 + (k0 & 15)] = (int8_t)qv;
+                    if ((k0 % G) == 0) a0.pack_s[((size_t)nt * ngx + g) * 16 + s] = scale;
+                }
+            }
+        }
     }
 }
 

@@ -944,6 +944,10 @@ struct AttnArgs {
     // batched decode: blockIdx.y = stream; float strides between streams (all 0 for the single-stream engine)
     long long sb_q, sb_kraw, sb_kv, sb_xb, sb_att;
     int tch;                  // K/V timesteps staged per LDS round (0 = attn_tch(hd))
+    // batched decode, per-kv-head kernel: also emit xb quantized (tensor.rs:91-119) in the packed MFMA operand order
+    int8_t* pack_q;
+    float* pack_s;
+    int group;
 };
 
 // LDS plan of k_attn (floats): q_s[hd] k_s[hd] raw[2hd] sq[2hd] opart[kWaves*hd] red[64] att[att_lds]
