@@ -148,6 +148,13 @@ int q3_generate_greedy_batch(q3_engine* e, const int32_t* first_tokens, const in
 /* Zero every stream's KV cache. */
 int q3_batch_reset_kv(q3_engine* e);
 
+/* q3_prefill with the prompt walked in blocks of up to 32 consecutive positions, each block ONE pass over the weights
+ * on the matrix cores; the positions read and write the engine's own KV cache (the one q3_forward uses).
+ * Sequential-equivalent: cache rows and the returned first generated token are bit-identical to q3_prefill, i.e. to
+ * the prompt loop of `chat` (generation.rs:116-123).  Same shape limits as q3_batch_init (Q3_ERR_UNSUPPORTED otherwise);
+ * does not need q3_batch_init (allocates the MFMA-ordered weight copy on first use, no per-stream caches). */
+int q3_prefill_batched(q3_engine* e, const int32_t* tokens, size_t n_tokens, size_t first_pos, int32_t* next_token);
+
 /* Parity tap: kind 0 key cache / 1 value cache ([n_layers][ctx][kv_dim]) / 2 residual stream x of one stream. */
 int q3_batch_read_state(q3_engine* e, int stream, int kind, size_t offset, size_t count, float* out);
 

@@ -356,12 +356,18 @@ __global__ __launch_bounds__(kBThreads) void k_bgemm(const BGemmArgs a) {
 // sum is walked in the reference order (layers.rs:346-419,495-506), so the result is bit-identical to k_attn in
 // reference-order mode; Q3_FLAG_FAST engines use this exact path too (exact is always admissible).
 // ------------------------------------------------------------------------------------------------
-constexpr int kGqaTch = 128;            // timesteps staged per LDS round
+constexpr int kGqaTch = 128;            // most timesteps staged per LDS round
 constexpr int kGqaSlots = 16;           // float4 staging registers per thread (tch*hd/4 <= slots * threads)
 __host__ __device__ inline int gqa_att_stride(int seq_len) { return (seq_len + 255) & ~255; }
+// timesteps per round: the workgroup's (kv_mul + 1) * 64 threads hold a chunk in kGqaSlots float4 registers each
+__host__ __device__ inline int gqa_tch(int hd, int kv_mul) {
+    int t = kGqaTch;
+    while (t > 8 && t * (hd / 4) > kGqaSlots * (kv_mul + 1) * 64) t >>= 1;
+    return t;
+}
 __host__ __device__ inline size_t attn_gqa_smem_bytes(int hd, int kv_mul, int seq_len) {
     const size_t nw = (size_t)kv_mul + 1;
-    return 4 * (nw * hd * 3 + (size_t)kv_mul * gqa_att_stride(seq_len) + (size_t)kGqaTch * (hd + kKPad));
+    return 4 * (nw * hd * 3 + (size_t)kv_mul * gqa_att_stride(seq_len) + (size_t)gqa_tch(hd, kv_mul) * (hd + kKPad));
 }
 
 __global__ __launch_bounds__(512) void k_attn_gqa(const AttnArgs a0) {
@@ -371,6 +377,7 @@ __global__ __launch_bounds__(512) void k_attn_gqa(const AttnArgs a0) {
     const size_t sbi = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = nw * 64;
     const bool kwave = wave == kv_mul;
+    const bool own_k = a0.k_in_cache == 0;         // decode: this kernel normalises + rotates the position's key row
     const int h = kvh * kv_mul + (kwave ? 0 : wave);
     const size_t kvd = (size_t)a0.n_kv_heads * hd;
     const int ast = gqa_att_stride(a0.seq_len);
@@ -399,7 +406,7 @@ __global__ __launch_bounds__(512) void k_attn_gqa(const AttnArgs a0) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int i = min(lane + 64 * u, hd - 1);
-        r[u] = kwave ? ksrc[i] : qsrc[i];
+        r[u] = kwave ? (own_k ? ksrc[i] : 0.0f) : qsrc[i];
     }
     RopeRegs rr;
     rope_regs_load(rr, kwave ? a0.k_norm_w : a0.q_norm_w, cs, hd);
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(512) void k_attn_gqa(const AttnArgs a0) {
             }
         }
     };
-    const int tch = kGqaTch;
+    const int tch = gqa_tch(hd, kv_mul);
     const int nch = (np + tch - 1) / tch;
     stage_issue_g(kbase, 0, min(tch, np));
 
@@ -437,9 +444,9 @@ __global__ __launch_bounds__(512) void k_attn_gqa(const AttnArgs a0) {
     for (int u = 0; u < 4; ++u)
         if (lane + 64 * u < hd) raw_w[lane + 64 * u] = r[u];
     wave_lds_sync();
-    wave_norm_rope(kwave ? k_s : q_s + wave * hd, raw_w, sq + wave * hd, rr, hd, 1);   // layers.rs:346-372
+    if (!kwave || own_k) wave_norm_rope(kwave ? k_s : q_s + wave * hd, raw_w, sq + wave * hd, rr, hd, 1);   // layers.rs:346-372
     __syncthreads();
-    if (kwave) {                                   // K is normalised + rotated in place in the cache
+    if (kwave && own_k) {                                   // K is normalised + rotated in place in the cache
         float* krow = key_cache + (size_t)pos * kvd + (size_t)kvh * hd;
         for (int i = lane; i < hd; i += 64) krow[i] = k_s[i];
     }
@@ -448,8 +455,8 @@ __global__ __launch_bounds__(512) void k_attn_gqa(const AttnArgs a0) {
     // ---- scores: att[t] = (q . K[t]) * scale                                   layers.rs:391-401
     for (int c = 0; c < nch; ++c) {
         const int t0 = c * tch, cnt = min(tch, np - t0);
-        stage_commit_g(kld, t0, cnt, pos);
-        if (pos >= t0 && pos < t0 + cnt)           // the current position's K comes from this kernel, not the cache
+        stage_commit_g(kld, t0, cnt, own_k ? pos : -1);
+        if (own_k && pos >= t0 && pos < t0 + cnt)  // the current position's K comes from this kernel, not the cache
             for (int i = tid; i < hd; i += nthr) buf[(pos - t0) * kld + i] = k_s[i];
         __syncthreads();
         if (c + 1 < nch) stage_issue_g(kbase, t0 + tch, min(tch, np - t0 - tch));     // next chunk under the dots
@@ -567,6 +574,41 @@ __global__ __launch_bounds__(512) void k_attn_gqa(const AttnArgs a0) {
                 }
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched prefill (T consecutive positions of ONE sequence per step, all sharing the engine's KV cache): the key
+// rows of the whole block must be in the cache before any position's attention runs, so QK-norm + RoPE of K
+// (layers.rs:346-372) gets its own small kernel.  grid (kv heads, positions), one wave each.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_knorm_rope(const AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[3 * 256];
+    const int hd = a.hd, kvh = blockIdx.x, lane = threadIdx.x;
+    const size_t sbi = blockIdx.y;
+    const int pos = a.st[sbi].pos;
+    const size_t kvd = (size_t)a.n_kv_heads * hd;
+    const float* ksrc = a.k_raw + sbi * a.sb_kraw + (size_t)kvh * hd;
+    float* raw = lds, *sq = lds + hd, *dst = lds + 2 * hd;
+    RopeRegs rr;
+    rope_regs_load(rr, a.k_norm_w, a.rope + (size_t)pos * hd, hd);
+    for (int i = lane; i < hd; i += 64) raw[i] = ksrc[i];
+    wave_lds_sync();
+    wave_norm_rope(dst, raw, sq, rr, hd, 1);
+    wave_lds_sync();
+    float* krow = a.key_cache + (size_t)pos * kvd + (size_t)kvh * hd;
+    for (int i = lane; i < hd; i += 64) krow[i] = dst[i];
+}
+
+// states of one prefill block: position first_pos + i takes prompt token base + i
+__global__ void k_set_prefill_states(State* st, const int32_t* prompt, int base, int first_pos, int n) {
+    const int i = threadIdx.x;
+    if (i < n) {
+        st[i].token = prompt[base + i];
+        st[i].pos = first_pos + base + i;
+        st[i].step = 0;
+        st[i].prompt_len = 0;
+        st[i].argmax = 0ull;
     }
 }
 

@@ -948,6 +948,7 @@ struct AttnArgs {
     int8_t* pack_q;
     float* pack_s;
     int group;
+    int k_in_cache;           // batched prefill: row pos of the key cache was already written by k_knorm_rope
 };
 
 // LDS plan of k_attn (floats): q_s[hd] k_s[hd] raw[2hd] sq[2hd] opart[kWaves*hd] red[64] att[att_lds]

@@ -18,7 +18,7 @@ _DIST_DIR = os.path.dirname(_PKG_DIR)
 EXPORTED_SYMBOLS = [
     "q3_create", "q3_get_config", "q3_forward", "q3_destroy", "q3_last_error", "q3_forward_argmax",
     "q3_generate_greedy", "q3_prefill", "q3_reset_kv", "q3_read_state", "q3_batch_init", "q3_forward_batch",
-    "q3_generate_greedy_batch", "q3_batch_reset_kv", "q3_batch_read_state", "q3_profile", "q3_profile_name", "q3_parse_header",
+    "q3_generate_greedy_batch", "q3_batch_reset_kv", "q3_batch_read_state", "q3_prefill_batched", "q3_profile", "q3_profile_name", "q3_parse_header",
     "q3_abi_version", "q3_op_quantize", "q3_op_dequantize", "q3_op_matmul", "q3_op_rmsnorm", "q3_op_softmax",
     "q3_op_swiglu", "q3_op_expf", "q3_op_attention", "q3_op_argmax",
 ]
@@ -86,6 +86,7 @@ def load_library() -> C.CDLL:
     L.q3_forward_argmax.argtypes = [C.c_void_p, sz, sz, C.POINTER(C.c_int32)]
     L.q3_generate_greedy.argtypes = [C.c_void_p, sz, sz, sz, C.POINTER(C.c_int32)]
     L.q3_prefill.argtypes = [C.c_void_p, C.POINTER(C.c_int32), sz, sz, C.POINTER(C.c_int32)]
+    L.q3_prefill_batched.argtypes = [C.c_void_p, C.POINTER(C.c_int32), sz, sz, C.POINTER(C.c_int32)]
     L.q3_reset_kv.argtypes = [C.c_void_p]
     L.q3_read_state.argtypes = [C.c_void_p, C.c_int, sz, sz, fp]
     i32p = C.POINTER(C.c_int32)
@@ -170,11 +171,13 @@ class Transformer:
         _check(rc)
         return [int(buf[i]) for i in range(n_tokens)]
 
-    def prefill(self, tokens, first_pos: int = 0) -> int:
-        """chat-mode prompt loop on the device (generation.rs:116-123); returns the first generated token."""
+    def prefill(self, tokens, first_pos: int = 0, batched: bool = False) -> int:
+        """chat-mode prompt loop on the device (generation.rs:116-123); returns the first generated token.
+        batched=True walks the prompt 32 positions per weight pass (q3_prefill_batched), same results."""
         arr = (C.c_int32 * len(tokens))(*[int(t) for t in tokens])
         out = C.c_int32(-1)
-        rc = self._lib.q3_prefill(self._h, arr, len(tokens), first_pos, C.byref(out))
+        fn = self._lib.q3_prefill_batched if batched else self._lib.q3_prefill
+        rc = fn(self._h, arr, len(tokens), first_pos, C.byref(out))
         if rc == -3:
             raise IndexError(self._lib.q3_last_error().decode(errors="replace"))
         _check(rc)

@@ -380,6 +380,34 @@ def test_batched_decode_long_positions(q3, tmp_path_factory):
             assert_biteq(lg[i], ref_logits[i], f"stream {i} logits at pos {pos0[i] + steps}")
 
 
+@pytest.mark.parametrize("shape_name,n_prompt,first_pos", [("tiny-g64", 41, 0), ("small-hd128", 70, 3), ("small-longctx", 333, 0)])
+def test_batched_prefill_is_sequential_equivalent(q3, shape_name, n_prompt, first_pos, tmp_path_factory):
+    """q3_prefill_batched (32 positions per weight pass, shared KV cache) == q3_prefill == the prompt loop of `chat`
+    (generation.rs:116-123): bit-identical cache rows, same first generated token, same continuation."""
+    ck = q3.checkpoint
+    shape = ck.SHAPES[shape_name]
+    path = str(tmp_path_factory.mktemp("pre") / f"{shape_name}.bin")
+    ck.write_synthetic_checkpoint(path, shape, seed=99)
+    prompt = ck.iter_prompt_tokens(shape, 5, n_prompt)
+    with q3.TransformerBuilder(path).with_ctx_length(512).build() as t:
+        want_first = t.prefill(prompt, first_pos)
+        want_rest = t.generate_greedy(want_first, first_pos + n_prompt, 6)
+        want_k, want_v = t.read_state("key"), t.read_state("value")
+    with q3.TransformerBuilder(path).with_ctx_length(512).build() as t:
+        got_first = t.prefill(prompt, first_pos, batched=True)
+        assert got_first == want_first
+        rest = t.generate_greedy(got_first, first_pos + n_prompt, 6)
+        assert rest == want_rest
+        assert_biteq(t.read_state("key"), want_k, "key cache after batched prefill + decode")
+        assert_biteq(t.read_state("value"), want_v, "value cache after batched prefill + decode")
+        # the batched decode API still works on the same engine afterwards (re-plans, own KV caches)
+        t.batch_init(2)
+        out = t.generate_greedy_batch([prompt[0], prompt[1]], [0, 0], 3)
+        assert out.shape == (2, 3)
+        with pytest.raises(IndexError):
+            t.prefill([1, 2, 10 ** 7], 0, batched=True)
+
+
 def test_batched_decode_error_behaviour(q3, tmp_path_factory):
     ck = q3.checkpoint
     path = str(tmp_path_factory.mktemp("bat") / "tiny-g64.bin")
