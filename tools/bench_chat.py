@@ -53,14 +53,27 @@ def main():
             if best is None or cur[0] + cur[1] < best[0] + best[1]:
                 best = cur
         pre_s, dec_s, first, toks = best
+        # the same prompt 32 positions per weight pass (int8 MFMA); must reproduce the sequential result exactly
+        t.prefill(prompt[:40], 0, batched=True)               # allocates the MFMA-ordered weight copy
+        bpre_s, bfirst = None, None
+        for _ in range(2):
+            t.reset_kv()
+            t0 = time.perf_counter()
+            bfirst = t.prefill(prompt, 0, batched=True)
+            dt = time.perf_counter() - t0
+            bpre_s = dt if bpre_s is None else min(bpre_s, dt)
+        btoks = t.generate_greedy(bfirst, a.prefill, a.decode)
+        same = (bfirst == first) and (btoks == toks)
         nbytes = os.path.getsize(path)
     print(json.dumps({
         "metric": "chat_prefill_decode_tokens_per_second", "unit": "tok/s", "n_gpus": 1,
-        "prefill_tok_s": round(a.prefill / pre_s, 2), "decode_tok_s": round(a.decode / dec_s, 2),
-        "prefill_ms_per_token": round(1e3 * pre_s / a.prefill, 4), "decode_ms_per_token": round(1e3 * dec_s / a.decode, 4),
+        "prefill_tok_s": round(a.prefill / bpre_s, 2), "prefill_sequential_tok_s": round(a.prefill / pre_s, 2),
+        "decode_tok_s": round(a.decode / dec_s, 2),
+        "batched_prefill_identical_to_sequential": bool(same),
+        "prefill_ms_per_token": round(1e3 * bpre_s / a.prefill, 4), "decode_ms_per_token": round(1e3 * dec_s / a.decode, 4),
         "decode_hbm_frac_of_8TBps": round(nbytes / (dec_s / a.decode) / 8e12, 4),
         "dtype": "int8 weights x int8 activations, f32 accumulate (reference order)", "data": "synthetic",
-        "config": {"workload": f"{a.shape} Q8 chat pattern: {a.prefill}-token sequential prefill + {a.decode}-token "
+        "config": {"workload": f"{a.shape} Q8 chat pattern: {a.prefill}-token prefill (32 positions per weight pass, sequential-equivalent) + {a.decode}-token "
                                f"greedy decode, ctx {a.ctx}", "checkpoint_bytes": nbytes, "seed": a.seed},
         "first_token": first, "last_token": toks[-1],
     }))
