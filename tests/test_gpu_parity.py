@@ -282,6 +282,34 @@ def test_long_context_split_attention_vs_oracle(q3, oracle, tmp_ckpt_dir):
             assert np.max(np.abs(a - b)) <= 2e-5
 
 
+def test_context_beyond_lds_score_rows_vs_oracle(q3, oracle, tmp_path_factory):
+    """seq_len > 4096: the single-kernel attention keeps its score rows in HBM instead of LDS (short positions), and the
+    split plan takes over at pos >= 256.  Both stay bit-identical to the oracle; q3_profile reports every family."""
+    import dataclasses
+    ck = q3.checkpoint
+    shape = dataclasses.replace(ck.SHAPES["small-longctx"], max_seq_len=8192)
+    path = str(tmp_path_factory.mktemp("ctx8k") / "small-ctx8k.bin")
+    ck.write_synthetic_checkpoint(path, shape, seed=6)
+    om = oracle.OracleModel(path)
+    with q3.TransformerBuilder(path).build() as t:
+        assert t.get_config().seq_len == 8192
+        tok = 9
+        for pos in [0, 1, 2, 100, 255, 256, 5000, 8191]:
+            a = np.array(t.forward(tok, pos), copy=True)
+            b = om.forward(tok, pos)
+            assert_biteq(a, b, f"pos {pos}")
+            tok = oracle.sample_argmax(b)
+        for pos in (3, 4000):
+            prof = t.profile(5, pos, 2)
+            names = [n for n, _, _ in prof]
+            assert names == ["qkv", "attn", "wo", "w13", "w2", "lm_head", "next"]
+            L = shape.n_layers
+            launches = {n: k for n, _, k in prof}
+            assert launches["qkv"] == 2 * L and launches["lm_head"] == 2 and launches["next"] == 2
+            assert launches["attn"] == (2 * L if pos < 256 else 4 * L)      # split plan: scores + out kernels
+            assert all(ms > 0 for _, ms, _ in prof)
+
+
 def test_device_prefill_matches_chat_pattern(q3, oracle):
     """q3_prefill == the prompt loop of `chat` (generation.rs:116-123): same KV rows, same first generated token, and
     decoding from there reproduces the oracle's chat turn."""
