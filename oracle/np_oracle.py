@@ -142,6 +142,57 @@ def argmax_last(logits: np.ndarray) -> int:
 
 
 # ---------------------------------------------------------------- models/qwen3.rs
+class NpSampler:
+    """sampler.rs:14-139, independent of the C restatement: Python integers for the xorshift64* stream, np.cumsum
+    (sequential f32) for the running sums, a key sort for the nucleus (ties: ascending index, see q3_oracle.h)."""
+    M = (1 << 64) - 1
+
+    def __init__(self, vocab_size: int, temperature: float, topp: float, rng_seed: int):
+        self.temperature, self.topp, self.state = f32(temperature), f32(topp), int(rng_seed) & self.M
+
+    def random_u32(self) -> int:
+        s = self.state
+        s ^= s >> 12
+        s ^= (s << 25) & self.M
+        s ^= s >> 27
+        self.state = s
+        return ((s * 0x2545F4914F6CDD1D) & self.M) >> 32
+
+    def random_f32(self):
+        return f32(f32(self.random_u32() >> 8) / f32(16777216.0))
+
+    @staticmethod
+    def sample_mult(p: np.ndarray, coin) -> int:
+        cdf = np.cumsum(p.astype(f32), dtype=f32)            # 0.0 + p0 == p0: same partial sums as the reference loop
+        hit = np.nonzero(f32(coin) < cdf)[0]
+        return int(hit[0]) if hit.size else max(p.size - 1, 0)
+
+    def sample_topp(self, p: np.ndarray, coin) -> int:
+        n = p.size
+        cutoff = f32(f32(1.0) - self.topp) / f32(max(n - 1, 1))
+        idx = np.nonzero(p >= cutoff)[0]
+        if idx.size == 0:
+            return 0
+        order = np.lexsort((idx, -p[idx].astype(np.float64)))   # prob descending, then index ascending
+        sp, si = p[idx][order].astype(f32), idx[order]
+        cum = np.cumsum(sp, dtype=f32)
+        over = np.nonzero(cum > self.topp)[0]
+        last = int(over[0]) if over.size else sp.size - 1
+        r = f32(f32(coin) * cum[last])
+        hit = np.nonzero(r < cum[: last + 1])[0]
+        return int(si[hit[0]]) if hit.size else int(si[last])
+
+    def sample(self, logits: np.ndarray) -> int:
+        lg = np.asarray(logits, dtype=f32)
+        if self.temperature == 0.0:
+            return argmax_last(lg)
+        p = softmax((lg / self.temperature).astype(f32))
+        coin = self.random_f32()
+        if self.topp <= 0.0 or self.topp >= 1.0:
+            return self.sample_mult(p, coin)
+        return self.sample_topp(p, coin)
+
+
 class NpQwen3:
     """Qwen3Transformer (models/qwen3.rs) over a checkpoint file (format: model_exporter.rs:164-316)."""
 

@@ -269,6 +269,75 @@ size_t q3o_sample_argmax(const float* logits, size_t n) {
     return best;
 }
 
+/* sampler.rs:44-54 */
+uint32_t q3o_random_u32(uint64_t* st) {
+    uint64_t s = *st;
+    s ^= s >> 12;
+    s ^= s << 25;
+    s ^= s >> 27;
+    *st = s;
+    return (uint32_t)((s * 0x2545F4914F6CDD1DULL) >> 32);
+}
+float q3o_random_f32(uint64_t* st) { return (float)(q3o_random_u32(st) >> 8) / 16777216.0f; }
+
+/* sampler.rs:62-71 */
+size_t q3o_sample_mult(const float* p, size_t n, float coin) {
+    float cdf = 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        cdf = cdf + p[i];
+        if (coin < cdf) return i;
+    }
+    return n ? n - 1 : 0; /* saturating_sub */
+}
+
+typedef struct { float prob; uint32_t index; } q3o_probindex;
+static int cmp_probindex_desc(const void* a, const void* b) {
+    const q3o_probindex* x = (const q3o_probindex*)a;
+    const q3o_probindex* y = (const q3o_probindex*)b;
+    const int32_t kx = total_key(x->prob), ky = total_key(y->prob);
+    if (kx != ky) return kx > ky ? -1 : 1;           /* b.prob.total_cmp(&a.prob): descending */
+    return x->index < y->index ? -1 : (x->index > y->index ? 1 : 0);   /* ties: ascending index (see header) */
+}
+
+/* sampler.rs:74-112 */
+size_t q3o_sample_topp(const float* p, size_t n, float topp, float coin) {
+    if (n == 0) return 0;
+    const size_t denom = (n - 1) > 1 ? (n - 1) : 1; /* saturating_sub(1).max(1) */
+    const float cutoff = (1.0f - topp) / (float)denom;
+    q3o_probindex* pi = (q3o_probindex*)malloc(sizeof(q3o_probindex) * n);
+    size_t n0 = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (p[i] >= cutoff) { pi[n0].prob = p[i]; pi[n0].index = (uint32_t)i; ++n0; }
+    qsort(pi, n0, sizeof(q3o_probindex), cmp_probindex_desc);
+    float cumulative = 0.0f;
+    size_t last_idx = n0 ? n0 - 1 : 0;
+    for (size_t i = 0; i < n0; ++i) {
+        cumulative = cumulative + pi[i].prob;
+        if (cumulative > topp) { last_idx = i; break; }
+    }
+    const float r = coin * cumulative;
+    float cdf = 0.0f;
+    size_t res = n0 ? pi[last_idx].index : 0;        /* n0 == 0: probindex[0] keeps its initial {0.0, 0} */
+    if (n0) {
+        for (size_t i = 0; i <= last_idx; ++i) {
+            cdf = cdf + pi[i].prob;
+            if (r < cdf) { res = pi[i].index; break; }
+        }
+    }
+    free(pi);
+    return res;
+}
+
+/* sampler.rs:118-139 */
+size_t q3o_sample(float* logits, size_t n, float temperature, float topp, uint64_t* rng_state) {
+    if (temperature == 0.0f) return q3o_sample_argmax(logits, n);
+    for (size_t i = 0; i < n; ++i) logits[i] = logits[i] / temperature;
+    q3o_softmax(logits, n);
+    const float coin = q3o_random_f32(rng_state);
+    if (topp <= 0.0f || topp >= 1.0f) return q3o_sample_mult(logits, n, coin);
+    return q3o_sample_topp(logits, n, topp, coin);
+}
+
 /* ------------------------------------------------------------------ exporter (format owner) */
 
 /* model_exporter.rs:321-338 */

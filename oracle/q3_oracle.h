@@ -80,6 +80,19 @@ void q3o_attention(float* xb, float* q, float* key_cache_layer, const float* val
 /* sampler.rs:57-59  last maximum under IEEE total order wins */
 size_t q3o_sample_argmax(const float* logits, size_t n);
 
+/* sampler.rs:44-54  xorshift64* stream; random_f32 = (u32 >> 8) / 2^24 in [0,1) */
+uint32_t q3o_random_u32(uint64_t* rng_state);
+float q3o_random_f32(uint64_t* rng_state);
+/* sampler.rs:62-71  first index whose running sum (from 0.0, index order) exceeds coin; else n-1 */
+size_t q3o_sample_mult(const float* probs, size_t n, float coin);
+/* sampler.rs:74-112  nucleus sampling.  The reference sorts the candidates with sort_unstable_by(total_cmp, descending):
+ * the order of EQUAL probabilities is unspecified there; this restatement (and the device) breaks ties by
+ * ascending token index. */
+size_t q3o_sample_topp(const float* probs, size_t n, float topp, float coin);
+/* sampler.rs:118-139  Sampler::sample: temperature 0 -> argmax; else logits /= T, softmax in place, one coin from
+ * the rng, then multinomial (topp <= 0 or >= 1) or top-p.  Mutates logits and rng_state like the reference. */
+size_t q3o_sample(float* logits, size_t n, float temperature, float topp, uint64_t* rng_state);
+
 /* ---- exporter side (format owner): model_exporter.rs ---- */
 /* :321-338 */
 float q3o_round_half_to_even(float x);

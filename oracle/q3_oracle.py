@@ -50,6 +50,17 @@ def lib() -> C.CDLL:
         L.q3o_attention.argtypes = [fp, fp, fp, fp, fp, fp, sz, sz, sz, sz]
         L.q3o_sample_argmax.argtypes = [fp, sz]
         L.q3o_sample_argmax.restype = sz
+        u64p = C.POINTER(C.c_uint64)
+        L.q3o_random_u32.argtypes = [u64p]
+        L.q3o_random_u32.restype = C.c_uint32
+        L.q3o_random_f32.argtypes = [u64p]
+        L.q3o_random_f32.restype = C.c_float
+        L.q3o_sample_mult.argtypes = [fp, sz, C.c_float]
+        L.q3o_sample_mult.restype = sz
+        L.q3o_sample_topp.argtypes = [fp, sz, C.c_float, C.c_float]
+        L.q3o_sample_topp.restype = sz
+        L.q3o_sample.argtypes = [fp, sz, C.c_float, C.c_float, u64p]
+        L.q3o_sample.restype = sz
         L.q3o_round_half_to_even.argtypes = [C.c_float]
         L.q3o_round_half_to_even.restype = C.c_float
         L.q3o_quantize_q80.argtypes = [i8p, fp, fp, fp, sz, sz]
@@ -162,6 +173,36 @@ def attention(q, key_layer, value_layer, q_norm_w, k_norm_w, pos, n_heads, n_kv_
 def sample_argmax(logits) -> int:
     logits = np.ascontiguousarray(logits, dtype=np.float32)
     return int(lib().q3o_sample_argmax(_fp(logits), logits.size))
+
+
+class Sampler:
+    """sampler.rs:14-139 (Sampler::new / sample): temperature, top-p and the xorshift64* stream."""
+
+    def __init__(self, vocab_size: int, temperature: float, topp: float, rng_seed: int):
+        assert vocab_size > 0 and temperature >= 0.0 and 0.0 <= topp <= 1.0
+        self.temperature, self.topp = float(temperature), float(topp)
+        self.rng_state = C.c_uint64(rng_seed)
+
+    def random_u32(self) -> int:
+        return int(lib().q3o_random_u32(C.byref(self.rng_state)))
+
+    def random_f32(self) -> float:
+        return float(lib().q3o_random_f32(C.byref(self.rng_state)))
+
+    def sample(self, logits) -> int:
+        """Mutates a private copy (the reference mutates the caller's buffer, which `generate` has already copied)."""
+        buf = np.array(logits, dtype=np.float32, copy=True)
+        return int(lib().q3o_sample(_fp(buf), buf.size, self.temperature, self.topp, C.byref(self.rng_state)))
+
+
+def sample_mult(probs, coin: float) -> int:
+    probs = np.ascontiguousarray(probs, dtype=np.float32)
+    return int(lib().q3o_sample_mult(_fp(probs), probs.size, coin))
+
+
+def sample_topp(probs, topp: float, coin: float) -> int:
+    probs = np.ascontiguousarray(probs, dtype=np.float32)
+    return int(lib().q3o_sample_topp(_fp(probs), probs.size, topp, coin))
 
 
 def round_half_to_even(x: float) -> float:

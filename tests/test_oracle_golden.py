@@ -249,3 +249,50 @@ def test_generate_mode_attends_over_zero_prefix(oracle):
     assert not k[:, :5].any() and not v[:, :5].any() and k[:, 5].any()
     b = oracle.OracleModel(golden_path("tiny.bin")).forward(9, 0)
     assert not np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Sampler (sampler.rs): xorshift64* stream, temperature / softmax, multinomial and nucleus sampling
+# ---------------------------------------------------------------------------------------------------------------
+def test_sampler_rng_stream_known_answers(oracle):
+    """random_u32 (sampler.rs:44-49) against an arbitrary-precision evaluation of the same recurrence."""
+    M = (1 << 64) - 1
+    for seed in (1, 42, 0xDEADBEEFCAFEBABE, M):
+        s = oracle.Sampler(8, 1.0, 0.9, seed)
+        st = seed
+        for _ in range(16):
+            st ^= st >> 12
+            st ^= (st << 25) & M
+            st ^= st >> 27
+            want = ((st * 0x2545F4914F6CDD1D) & M) >> 32
+            assert s.random_u32() == want
+        f = s.random_f32()
+        assert 0.0 <= f < 1.0 and f * 16777216.0 == int(f * 16777216.0)      # (u32 >> 8) / 2^24
+
+
+def test_sampler_c_and_numpy_restatements_agree(oracle, np_oracle):
+    rng = np.random.default_rng(3)
+    for n, sigma, temp, topp in [(50, 1.0, 1.0, 0.9), (1000, 3.0, 0.7, 0.95), (1000, 0.01, 1.3, 0.5), (4096, 2.0, 0.6, 1.0),
+                                 (4096, 2.0, 0.6, 0.0), (300, 5.0, 0.2, 0.3), (7, 1.0, 2.0, 0.99)]:
+        a, b = oracle.Sampler(n, temp, topp, 1234), np_oracle.NpSampler(n, temp, topp, 1234)
+        for _ in range(25):
+            lg = rng.normal(0.0, sigma, n).astype(np.float32)
+            lg[rng.integers(0, n, 5)] = lg[0]                                 # exact ties among the candidates
+            assert a.sample(lg) == b.sample(lg)
+        assert a.rng_state.value == b.state
+
+
+def test_sampler_edge_cases(oracle):
+    lg = np.array([0.5, 2.0, -1.0, 2.0], dtype=np.float32)
+    assert oracle.Sampler(4, 0.0, 0.9, 5).sample(lg) == 3                      # temperature 0: last maximum, no coin drawn
+    s = oracle.Sampler(4, 0.0, 0.9, 5)
+    s.sample(lg)
+    assert s.rng_state.value == 5
+    p = np.array([0.1, 0.2, 0.3, 0.4], dtype=np.float32)
+    assert oracle.sample_mult(p, 0.0) == 0 and oracle.sample_mult(p, 0.1) == 1     # coin < cdf is strict
+    assert oracle.sample_mult(p, 0.999999) == 3 and oracle.sample_mult(p * 0.5, 0.9) == 3    # falls off the end -> n-1
+    # nucleus: sorted 0.4,0.3,0.2,0.1; topp 0.5 keeps {0.4,0.3} (cum 0.7 > 0.5 at i=1); r = coin*0.7
+    assert oracle.sample_topp(p, 0.5, 0.0) == 3 and oracle.sample_topp(p, 0.5, 0.99) == 2
+    assert oracle.sample_topp(p, 0.5, 0.5) == 3 and oracle.sample_topp(p, 0.5, 0.6) == 2      # r = .35 < .4 ; r = .42 -> second
+    tie = np.array([0.25, 0.25, 0.25, 0.25], dtype=np.float32)
+    assert oracle.sample_topp(tie, 0.6, 0.0) == 0 and oracle.sample_topp(tie, 0.6, 0.4) == 1   # ties: ascending index
