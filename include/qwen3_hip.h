@@ -103,6 +103,20 @@ int q3_generate_greedy(q3_engine* e, size_t first_token, size_t first_pos, size_
  * generated token -- is returned.  Continue with q3_generate_greedy(e, *next_token, first_pos + n_tokens, ...). */
 int q3_prefill(q3_engine* e, const int32_t* tokens, size_t n_tokens, size_t first_pos, int32_t* next_token);
 
+/* Sampler::new(vocab_size, temperature, topp, rng_seed) + Sampler::sample on the device (sampler.rs:29-42,118-139):
+ * temperature scaling, softmax, one xorshift64* coin per draw, multinomial (topp <= 0 or >= 1) or top-p.  After this
+ * call with temperature > 0, every token the engine draws itself -- q3_forward_argmax / q3_forward_sample,
+ * q3_generate_greedy / q3_generate_sampled, and the last position of q3_prefill / q3_prefill_batched -- comes from
+ * Sampler::sample instead of the argmax, and a chat-mode prefill advances the rng by one coin per prompt position like
+ * the reference's discarded samples (generation.rs:116-123).  temperature 0 restores the argmax path (no coin drawn).
+ * All running sums are walked in the reference's order (bit-identical probabilities and tokens); candidates of EQUAL
+ * probability in top-p are ordered by ascending token id (the reference's sort_unstable_by leaves that unspecified).
+ * q3_forward() is unaffected: it returns logits and leaves sampling to the caller.  Batched decode stays greedy. */
+int q3_sampler_set(q3_engine* e, float temperature, float topp, uint64_t rng_seed);
+int q3_sampler_get_rng(q3_engine* e, uint64_t* rng_state);
+int q3_forward_sample(q3_engine* e, size_t token, size_t pos, int32_t* next_token);
+int q3_generate_sampled(q3_engine* e, size_t first_token, size_t first_pos, size_t n_tokens, int32_t* out_tokens);
+
 /* Fresh-engine state: zero the KV cache (models/qwen3.rs:439-440) */
 int q3_reset_kv(q3_engine* e);
 

@@ -27,6 +27,7 @@
 #include "../../include/qwen3_hip.h"
 #include "q3_kernels.h"
 #include "q3_batch.h"
+#include "q3_sampler.h"
 
 namespace {
 
@@ -206,6 +207,13 @@ struct q3_engine {
     int att_stride = 0;
     int split_pos = 256;
     BatchCtx* batch = nullptr;                 // batched decode state (q3_batch_init), see q3_batch_host.inc
+    // device-side Sampler (q3_sampler_set): temperature > 0 makes every token draw go through k_sample
+    bool sampling = false;
+    SamplerState* d_sampler = nullptr;
+    float *d_probs = nullptr, *d_sp = nullptr;
+    unsigned long long* d_keys = nullptr;
+    SampleArgs sargs{};
+    int enqueue_sample();
 
     int load(const char* path, uint32_t ctx_len);
     int build_plan();
@@ -274,7 +282,7 @@ void q3_engine::release() {
     if (graph) (void)hipGraphDestroy(graph);
     if (graph_long_exec) (void)hipGraphExecDestroy(graph_long_exec);
     if (graph_long) (void)hipGraphDestroy(graph_long);
-    void* dptrs[] = {d_prompt, d_att_priv, d_argmax_slots, d_stamps, d_blob, d_x, d_q, d_kraw, d_xb, d_hb, d_logits, d_tap, d_key, d_value, d_rope, d_att, d_state, d_out_tokens};
+    void* dptrs[] = {d_sampler, d_probs, d_sp, d_keys, d_prompt, d_att_priv, d_argmax_slots, d_stamps, d_blob, d_x, d_q, d_kraw, d_xb, d_hb, d_logits, d_tap, d_key, d_value, d_rope, d_att, d_state, d_out_tokens};
     for (void* p : dptrs)
         if (p) (void)hipFree(p);
     if (h_logits) (void)hipHostFree(h_logits);
@@ -666,6 +674,14 @@ int q3_engine::enqueue_forward(bool eager, size_t pos) {
         for (const Launch& L : (lng ? plan_long : plan)) launch_one(L, this);
         HIP_TRY(hipGetLastError());
     }
+    return enqueue_sample();
+}
+
+// Sampler::sample on the logits of the forward just enqueued (after k_next has advanced the state)
+int q3_engine::enqueue_sample() {
+    if (!sampling) return Q3_OK;
+    hipLaunchKernelGGL(k_sample, dim3(1), dim3(kSampThreads), 0, stream, sargs);
+    HIP_TRY(hipGetLastError());
     return Q3_OK;
 }
 
@@ -840,6 +856,58 @@ int q3_prefill(q3_engine* e, const int32_t* tokens, size_t n_tokens, size_t firs
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (next_token) *next_token = e->h_tokens[0];
     return Q3_OK;
+}
+
+int q3_sampler_set(q3_engine* e, float temperature, float topp, uint64_t rng_seed) {
+    g_err[0] = 0;
+    if (!e) return fail(Q3_ERR_ARG, "null engine");
+    if (!(temperature >= 0.0f)) return fail(Q3_ERR_ARG, "Temperature must be non-negative");            // sampler.rs:32
+    if (!(topp >= 0.0f && topp <= 1.0f)) return fail(Q3_ERR_ARG, "Top-p must be between 0.0 and 1.0");  // sampler.rs:33
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const int n = e->cfg.vocab_size;
+    const int blen = 4 * ((n + 4095) / 4096);
+    if (!e->d_sampler) {
+        size_t n2 = 1;
+        while (n2 < (size_t)n) n2 <<= 1;
+        HIP_TRY(hipMalloc((void**)&e->d_sampler, sizeof(SamplerState)));
+        HIP_TRY(hipMalloc((void**)&e->d_probs, 4 * (size_t)kSampThreads * blen));
+        HIP_TRY(hipMalloc((void**)&e->d_sp, 4 * (size_t)kSampThreads * blen));
+        HIP_TRY(hipMalloc((void**)&e->d_keys, 8 * n2));
+    }
+    SamplerState h{rng_seed, temperature, topp};
+    HIP_TRY(hipMemcpy(e->d_sampler, &h, sizeof(h), hipMemcpyHostToDevice));
+    SampleArgs a{};
+    a.logits = e->d_logits;
+    a.n = n;
+    a.blen = blen;
+    a.probs = e->d_probs;
+    a.keys = e->d_keys;
+    a.sp = e->d_sp;
+    a.ss = e->d_sampler;
+    a.st = e->d_state;
+    a.out_tokens = e->d_out_tokens;
+    a.out_cap = e->out_cap;
+    e->sargs = a;
+    e->sampling = temperature != 0.0f;                       // sampler.rs:119-120: temperature 0 is the argmax path
+    return Q3_OK;
+}
+
+int q3_sampler_get_rng(q3_engine* e, uint64_t* rng_state) {
+    g_err[0] = 0;
+    if (!e || !rng_state || !e->d_sampler) return fail(Q3_ERR_ARG, "q3_sampler_set has not been called");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    SamplerState h;
+    HIP_TRY(hipMemcpy(&h, e->d_sampler, sizeof(h), hipMemcpyDeviceToHost));
+    *rng_state = h.rng;
+    return Q3_OK;
+}
+
+int q3_forward_sample(q3_engine* e, size_t token, size_t pos, int32_t* next_token) { return q3_forward_argmax(e, token, pos, next_token); }
+
+int q3_generate_sampled(q3_engine* e, size_t first_token, size_t first_pos, size_t n_tokens, int32_t* out_tokens) {
+    return q3_generate_greedy(e, first_token, first_pos, n_tokens, out_tokens);
 }
 
 int q3_reset_kv(q3_engine* e) {

@@ -1,0 +1,263 @@
+// Device-side Sampler::sample (qwen3-inference/src/sampler.rs:118-139): temperature, softmax, one xorshift64* coin,
+// multinomial or top-p -- so that non-greedy decoding does not ship 607 KB of logits to the host per token.
+//
+// One workgroup of 1024 threads per token.  Everything order-sensitive in the reference is a running f32 sum walked in
+// index order (softmax denominator layers.rs:495-506, cdf sampler.rs:62-71, nucleus cumulative + cdf sampler.rs:90-110).
+// wg_exact_prefix() reproduces those sums exactly: lane j owns block j of the (zero padded) sequence, folds it from a
+// GUESSED input, the guesses are corrected with a scan of the link mismatches and every link is verified bitwise
+// (the scheme of seq_sum_blocks in q3_kernels.h, over 1024 lanes); afterwards every lane knows the exact running sum
+// before and after its block, and "first index whose running sum crosses x" is a ballot plus one short in-block walk.
+//
+// Top-p sorts the candidates by (probability descending, index ascending).  The reference uses sort_unstable_by, which
+// leaves the order of EQUAL probabilities unspecified; the CPU restatement used by the tests makes the same choice.
+#pragma once
+#include "q3_kernels.h"
+
+namespace q3 {
+
+constexpr int kSampThreads = 1024;
+
+struct SamplerState {
+    unsigned long long rng;   // sampler.rs:19 rng_state
+    float temperature;
+    float topp;
+};
+
+struct SampleArgs {
+    const float* logits;      // [n]
+    int n;                    // vocab size
+    int blen;                 // terms per lane block: 4 * ceil(n / 4096); 1024 * blen >= n
+    float* probs;             // [1024 * blen] scratch: e, then p (zero padded)
+    unsigned long long* keys; // [n2] sort scratch, n2 = next power of two >= n
+    float* sp;                // [1024 * blen] sorted candidate probabilities (zero padded)
+    SamplerState* ss;
+    State* st;
+    int32_t* out_tokens;
+    int out_cap;
+};
+
+__device__ __forceinline__ float key_to_float(unsigned k) {
+    const unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;    // inverse of total_order_key
+    return __uint_as_float(b);
+}
+
+// inclusive scan of one float per thread over the whole workgroup (any association: guesses / corrections only)
+__device__ __forceinline__ float wg_scan_incl(float v, float* wtot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v += dpp_f<0x111>(v);
+    v += dpp_f<0x112>(v);
+    v += dpp_f<0x114>(v);
+    v += dpp_f<0x118>(v);
+    const float r0 = __shfl(v, 15), r1 = __shfl(v, 31), r2 = __shfl(v, 47);
+    const int row = lane >> 4;
+    if (row == 1) v += r0;
+    else if (row == 2) v += r0 + r1;
+    else if (row == 3) v += (r0 + r1) + r2;
+    __syncthreads();
+    if (lane == 63) wtot[wave] = v;
+    __syncthreads();
+    float off = 0.0f;
+    for (int w = 0; w < wave; ++w) off += wtot[w];
+    return v + off;
+}
+
+// Exact running sums of t[0 .. 1024*blen) (non-negative terms, blen % 4 == 0) folded in index order from `init`:
+// lane j returns in_j = sum before its block [j*blen, (j+1)*blen) and out_j = sum after it, both bit-exact.
+// xch: >= 1024 + 16 floats of LDS.  Every thread of the 1024-thread workgroup must call it.
+__device__ __forceinline__ void wg_exact_prefix(const float* t, int blen, float init, float* xch, float& in_j, float& out_j) {
+    const int j = threadIdx.x;
+    const v4f* blk = (const v4f*)(t + (size_t)j * blen);
+    const int nq = blen >> 2;
+    float* wtot = xch + kSampThreads;
+    // approximate block total (any order)
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+    for (int q = 0; q < nq; ++q) {
+        const v4f v = blk[q];
+        p0 += v.x; p1 += v.y; p2 += v.z; p3 += v.w;
+    }
+    const float tot = (p0 + p1) + (p2 + p3);
+    float g = init + (wg_scan_incl(tot, wtot) - tot);      // guessed input of block j
+    if (j == 0) g = init;
+    float out = seq_chain(g, blk, nq);
+    for (int round = 0; round < kSampThreads + 1; ++round) {
+        __syncthreads();
+        xch[j] = out;
+        __syncthreads();
+        float e = (j == 0) ? 0.0f : xch[j - 1] - g;         // mismatch at link j
+        e = wg_scan_incl(e, wtot);
+        float sc = g + e;
+        if (j == 0) sc = init;
+        const float out2 = seq_chain(sc, blk, nq);
+        __syncthreads();
+        xch[j] = out2;
+        __syncthreads();
+        const bool ok = (j == 0) || (__float_as_uint(xch[j - 1]) == __float_as_uint(sc));
+        g = sc;
+        out = out2;
+        if (__syncthreads_and(ok)) break;                   // block 0 is exact by construction; round r fixes block r
+    }
+    in_j = g;
+    out_j = out;
+}
+
+// first index i (in sequence order) whose running sum c_i satisfies (GT ? c_i > x : x < c_i) -- the same comparison;
+// returns -1 if none.  cum receives c_i (or the total when none).  red: 2 ints + 1 float of LDS.
+__device__ __forceinline__ int wg_first_crossing(const float* t, int blen, float in_j, float out_j, float x, int* red, float* cum) {
+    const int j = threadIdx.x;
+    __syncthreads();                                        // a previous call's results have been consumed
+    if (j == 0) { red[0] = 0x7fffffff; red[1] = -1; }
+    __syncthreads();
+    if (x < out_j) atomicMin(&red[0], j);                   // running sums are non-decreasing: first lane whose block crosses
+    __syncthreads();
+    const int lane_hit = red[0];
+    if (lane_hit == 0x7fffffff) {
+        if (j == kSampThreads - 1) *(float*)&red[2] = out_j;
+        __syncthreads();
+        *cum = *(float*)&red[2];
+        return -1;
+    }
+    if (j == lane_hit) {
+        float c = in_j;
+        const float* b = t + (size_t)j * blen;
+        int i = 0;
+        for (; i < blen; ++i) {
+            c = c + b[i];
+            if (x < c) break;
+        }
+        red[1] = j * blen + i;
+        *(float*)&red[2] = c;
+    }
+    __syncthreads();
+    *cum = *(float*)&red[2];
+    return red[1];
+}
+
+__global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a) {
+    __shared__ float xch[kSampThreads + 16];
+    __shared__ int red[4];
+    __shared__ float fred[16];
+    __shared__ int ired[20];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    State* st = a.st;
+    SamplerState* ss = a.ss;
+    const float temperature = ss->temperature, topp = ss->topp;
+
+    // prompt positions of a chat-mode prefill: the reference draws (and discards) a sample per prompt token, which
+    // advances the rng by exactly one coin; the input of the next forward stays the prompt token k_next selected
+    const bool discard = st->step < st->prompt_len;
+    __syncthreads();
+    unsigned long long rs = ss->rng;
+    rs ^= rs >> 12;
+    rs ^= rs << 25;
+    rs ^= rs >> 27;                                               // sampler.rs:44-49
+    const unsigned r32 = (unsigned)((rs * 0x2545F4914F6CDD1Dull) >> 32);
+    const float coin = (float)(r32 >> 8) / 16777216.0f;          // sampler.rs:52-54
+    __syncthreads();
+    if (tid == 0) ss->rng = rs;
+    if (discard) return;
+
+    const int n = a.n, blen = a.blen, npad = kSampThreads * blen;
+    // ---- logits / temperature, max                                              sampler.rs:124-126, layers.rs:496
+    float m = -__builtin_inff();
+    for (int i = tid; i < n; i += kSampThreads) m = fmaxf(m, a.logits[i] / temperature);
+    m = group_max_f32(m, 64);
+    if (lane == 0) fred[wave] = m;
+    __syncthreads();
+    m = fred[0];
+    for (int w = 1; w < kSampThreads / 64; ++w) m = fmaxf(m, fred[w]);
+    // ---- e = exp(x - max), exact sum in index order, p = e * (1/sum)             layers.rs:497-505
+    for (int i = tid; i < npad; i += kSampThreads) a.probs[i] = (i < n) ? q3_expf(a.logits[i] / temperature - m) : 0.0f;
+    __syncthreads();
+    float in_j, out_j;
+    wg_exact_prefix(a.probs, blen, -0.0f, xch, in_j, out_j);     // Iterator::sum from -0.0
+    __syncthreads();
+    if (tid == kSampThreads - 1) fred[0] = out_j;
+    __syncthreads();
+    const float inv = 1.0f / fred[0];
+    __syncthreads();
+    for (int i = tid; i < n; i += kSampThreads) a.probs[i] = a.probs[i] * inv;
+    __syncthreads();
+
+    int result;
+    if (topp <= 0.0f || topp >= 1.0f) {
+        // ---- sample_mult: first i with coin < cdf_i, cdf from 0.0                 sampler.rs:62-71
+        wg_exact_prefix(a.probs, blen, 0.0f, xch, in_j, out_j);
+        float cum;
+        const int hit = wg_first_crossing(a.probs, blen, in_j, out_j, coin, red, &cum);
+        result = (hit >= 0 && hit < n) ? hit : n - 1;
+    } else {
+        // ---- sample_topp                                                          sampler.rs:74-112
+        const float cutoff = (1.0f - topp) / (float)((n - 1) > 1 ? (n - 1) : 1);
+        // candidates in index order: lane j owns indices [j*blen, (j+1)*blen)
+        int cnt = 0;
+        const int i0 = tid * blen;
+        for (int i = i0; i < min(i0 + blen, n); ++i) cnt += (a.probs[i] >= cutoff) ? 1 : 0;
+        // exclusive scan of counts over the workgroup
+        int inc = cnt;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) ired[wave] = inc;
+        __syncthreads();
+        int off = 0;
+        for (int w = 0; w < wave; ++w) off += ired[w];
+        int n0 = 0;
+        for (int w = 0; w < kSampThreads / 64; ++w) n0 += ired[w];
+        int pos = off + inc - cnt;
+        for (int i = i0; i < min(i0 + blen, n); ++i) {
+            const float p = a.probs[i];
+            if (p >= cutoff) a.keys[pos++] = ((unsigned long long)total_order_key(p) << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+        }
+        int n2 = 1;
+        while (n2 < n0) n2 <<= 1;
+        for (int i = n0 + tid; i < n2; i += kSampThreads) a.keys[i] = 0ull;       // below every real key
+        __syncthreads();
+        // bitonic sort, descending: probability first, then ascending index (see header)
+        for (int k = 2; k <= n2; k <<= 1) {
+            for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                for (int i = tid; i < n2; i += kSampThreads) {
+                    const int l = i ^ jj;
+                    if (l > i) {
+                        const unsigned long long x = a.keys[i], y = a.keys[l];
+                        const bool desc = (i & k) == 0;
+                        if (desc ? (x < y) : (x > y)) { a.keys[i] = y; a.keys[l] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int i = tid; i < npad; i += kSampThreads) a.sp[i] = (i < n0) ? key_to_float((unsigned)(a.keys[i] >> 32)) : 0.0f;
+        __syncthreads();
+        // cumulative probability in sorted order, truncation point, then the cdf walk with r = coin * cumulative
+        wg_exact_prefix(a.sp, blen, 0.0f, xch, in_j, out_j);
+        float cumulative;
+        int last_idx = wg_first_crossing(a.sp, blen, in_j, out_j, topp, red, &cumulative);   // first cum > topp
+        if (last_idx < 0 || last_idx >= n0) last_idx = n0 - 1;                              // (cumulative = total then)
+        __syncthreads();
+        const float r = coin * cumulative;
+        float dummy;
+        int hit = wg_first_crossing(a.sp, blen, in_j, out_j, r, red, &dummy);               // first r < cdf
+        if (hit < 0 || hit > last_idx) hit = last_idx;
+        result = (n0 > 0) ? (int)(0xffffffffu - (unsigned)(a.keys[hit] & 0xffffffffull)) : 0;
+    }
+    if (tid == 0) {
+        // k_next already advanced (pos, step) and stored the argmax: the sampled token replaces it
+        st->token = result;
+        const int s = st->step - 1;
+        if (s >= 0 && s < a.out_cap) a.out_tokens[s] = result;
+    }
+}
+
+// advance the xorshift64* stream by `count` coins (batched prefill: one discarded sample per prompt position)
+__global__ void k_rng_skip(SamplerState* ss, int count) {
+    unsigned long long rs = ss->rng;
+    for (int i = 0; i < count; ++i) {
+        rs ^= rs >> 12;
+        rs ^= rs << 25;
+        rs ^= rs >> 27;
+    }
+    ss->rng = rs;
+}
+
+}  // namespace q3

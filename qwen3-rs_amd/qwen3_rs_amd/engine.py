@@ -18,7 +18,7 @@ _DIST_DIR = os.path.dirname(_PKG_DIR)
 EXPORTED_SYMBOLS = [
     "q3_create", "q3_get_config", "q3_forward", "q3_destroy", "q3_last_error", "q3_forward_argmax",
     "q3_generate_greedy", "q3_prefill", "q3_reset_kv", "q3_read_state", "q3_batch_init", "q3_forward_batch",
-    "q3_generate_greedy_batch", "q3_batch_reset_kv", "q3_batch_read_state", "q3_prefill_batched", "q3_profile", "q3_profile_name", "q3_parse_header",
+    "q3_generate_greedy_batch", "q3_batch_reset_kv", "q3_batch_read_state", "q3_prefill_batched", "q3_sampler_set", "q3_sampler_get_rng", "q3_forward_sample", "q3_generate_sampled", "q3_profile", "q3_profile_name", "q3_parse_header",
     "q3_abi_version", "q3_op_quantize", "q3_op_dequantize", "q3_op_matmul", "q3_op_rmsnorm", "q3_op_softmax",
     "q3_op_swiglu", "q3_op_expf", "q3_op_attention", "q3_op_argmax",
 ]
@@ -87,6 +87,10 @@ def load_library() -> C.CDLL:
     L.q3_generate_greedy.argtypes = [C.c_void_p, sz, sz, sz, C.POINTER(C.c_int32)]
     L.q3_prefill.argtypes = [C.c_void_p, C.POINTER(C.c_int32), sz, sz, C.POINTER(C.c_int32)]
     L.q3_prefill_batched.argtypes = [C.c_void_p, C.POINTER(C.c_int32), sz, sz, C.POINTER(C.c_int32)]
+    L.q3_sampler_set.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_uint64]
+    L.q3_sampler_get_rng.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.q3_forward_sample.argtypes = [C.c_void_p, sz, sz, C.POINTER(C.c_int32)]
+    L.q3_generate_sampled.argtypes = [C.c_void_p, sz, sz, sz, C.POINTER(C.c_int32)]
     L.q3_reset_kv.argtypes = [C.c_void_p]
     L.q3_read_state.argtypes = [C.c_void_p, C.c_int, sz, sz, fp]
     i32p = C.POINTER(C.c_int32)
@@ -181,6 +185,16 @@ class Transformer:
         if rc == -3:
             raise IndexError(self._lib.q3_last_error().decode(errors="replace"))
         _check(rc)
+        return int(out.value)
+
+    def set_sampler(self, temperature: float, topp: float, rng_seed: int):
+        """Sampler::new (sampler.rs:29-42) on the device: subsequent forward_argmax / generate_greedy / prefill calls draw
+        with Sampler::sample; temperature 0 restores greedy decoding."""
+        _check(self._lib.q3_sampler_set(self._h, temperature, topp, rng_seed))
+
+    def sampler_rng_state(self) -> int:
+        out = C.c_uint64(0)
+        _check(self._lib.q3_sampler_get_rng(self._h, C.byref(out)))
         return int(out.value)
 
     def reset_kv(self):

@@ -20,6 +20,8 @@ def oracle():
     from oracle import q3_oracle
     q3_oracle.build()
     q3_oracle.lib()
+    # the test models are small: with one OpenMP thread per core of a 128-core GPU host a forward takes seconds
+    q3_oracle.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
     return q3_oracle
 
 

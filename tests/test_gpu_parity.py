@@ -460,6 +460,67 @@ def test_batched_decode_error_behaviour(q3, tmp_path_factory):
         assert ei.value.code == -5
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Device-side Sampler::sample (sampler.rs:118-139)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("temperature,topp", [(0.7, 0.9), (1.0, 1.0), (1.3, 0.0), (0.3, 0.5), (2.0, 0.99)])
+def test_device_sampler_matches_oracle(q3, oracle, temperature, topp, tmp_path_factory):
+    """q3_sampler_set + forward_argmax/generate: the device draws token by token exactly what Sampler::sample draws from
+    the same logits and the same xorshift64* stream (softmax denominator, cdf and nucleus sums in index order)."""
+    ck = q3.checkpoint
+    shape = ck.SHAPES["small-hd128"]                                   # vocab 2048: top-p keeps hundreds of candidates
+    path = str(tmp_path_factory.mktemp("samp") / "small-hd128.bin")
+    ck.write_synthetic_checkpoint(path, shape, seed=31)
+    seed = 0x1234ABCD5678EF01
+    om = oracle.OracleModel(path)
+    smp = oracle.Sampler(shape.vocab_size, temperature, topp, seed)
+    with q3.TransformerBuilder(path).build() as t:
+        t.set_sampler(temperature, topp, seed)
+        tok, want = 17, []
+        for pos in range(0, 40):                                       # step by step: forward + sample on the device
+            nxt = smp.sample(om.forward(tok, pos))
+            got = t.forward_argmax(tok, pos)
+            assert got == nxt, f"pos {pos}"
+            want.append(nxt)
+            tok = nxt
+        assert t.sampler_rng_state() == smp.rng_state.value
+        # the device-resident loop draws the same sequence
+        t.reset_kv()
+        t.set_sampler(temperature, topp, seed)
+        assert t.generate_greedy(17, 0, 40) == want
+        # temperature 0 restores the argmax path and draws no coin
+        t.set_sampler(0.0, topp, 99)
+        t.reset_kv()
+        om.reset()
+        lg = om.forward(5, 0)
+        assert t.forward_argmax(5, 0) == oracle.sample_argmax(lg)
+        assert t.sampler_rng_state() == 99
+
+
+def test_device_sampler_large_vocab_and_prefill(q3, oracle, tmp_path_factory):
+    """Vocabulary 16384 (many blocks per lane, thousands of nucleus candidates incl. exact ties) on raw logits through
+    the full engine, and the chat-mode prefill: one discarded coin per prompt position, sequential and batched."""
+    ck = q3.checkpoint
+    shape = ck.SHAPES["qwen3-4b-dims-l2"]
+    path = str(tmp_path_factory.mktemp("samp") / "4b-l2.bin")
+    ck.write_synthetic_checkpoint(path, shape, seed=8)
+    om = oracle.OracleModel(path)
+    prompt = ck.iter_prompt_tokens(shape, 3, 37)
+    for temperature, topp in [(0.8, 0.95), (1.0, 1.0)]:
+        seed = 424242
+        smp = oracle.Sampler(shape.vocab_size, temperature, topp, seed)
+        om.reset()
+        want_tokens, pos, _ = q3.chat_turn(om, prompt, 0, 6, sample=smp.sample)
+        with q3.TransformerBuilder(path).with_ctx_length(256).build() as t:
+            for batched in (False, True):
+                t.reset_kv()
+                t.set_sampler(temperature, topp, seed)
+                first = t.prefill(prompt, 0, batched=batched)
+                assert first == want_tokens[0], f"batched={batched}"
+                rest = t.generate_greedy(first, len(prompt), 5)
+                assert [first] + rest == want_tokens, f"batched={batched}"
+
+
 def test_two_engines_are_independent(q3):
     """Replicas: engines share nothing (own stream, KV cache, scratch, graphs).  Interleaving two engines -- here on one
     device -- gives each exactly the tokens it produces alone."""
