@@ -137,6 +137,7 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a) {
     __shared__ int red[4];
     __shared__ float fred[16];
     __shared__ int ired[20];
+    __shared__ float hmass[2048];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     State* st = a.st;
     SamplerState* ss = a.ss;
@@ -188,57 +189,90 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a) {
     } else {
         // ---- sample_topp                                                          sampler.rs:74-112
         const float cutoff = (1.0f - topp) / (float)((n - 1) > 1 ? (n - 1) : 1);
-        // candidates in index order: lane j owns indices [j*blen, (j+1)*blen)
-        int cnt = 0;
-        const int i0 = tid * blen;
-        for (int i = i0; i < min(i0 + blen, n); ++i) cnt += (a.probs[i] >= cutoff) ? 1 : 0;
-        // exclusive scan of counts over the workgroup
-        int inc = cnt;
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(inc, d);
-            if (lane >= d) inc += o;
-        }
-        if (lane == 63) ired[wave] = inc;
+        const int i0 = tid * blen, i1 = min(i0 + blen, n);
+        // Only the head of the sorted candidate list is ever walked (until the cumulative probability exceeds topp), and
+        // "all candidates whose probability key is >= T" is exactly a prefix of that list for any T.  A 2048-bin
+        // histogram of the keys (mass per bin, any order: heuristic only) picks a T that should cover topp; if the exact
+        // walk over that prefix does not cross topp after all, the second attempt sorts every candidate.
+        for (int i = tid; i < 2048; i += kSampThreads) hmass[i] = 0.0f;
         __syncthreads();
-        int off = 0;
-        for (int w = 0; w < wave; ++w) off += ired[w];
-        int n0 = 0;
-        for (int w = 0; w < kSampThreads / 64; ++w) n0 += ired[w];
-        int pos = off + inc - cnt;
-        for (int i = i0; i < min(i0 + blen, n); ++i) {
+        for (int i = i0; i < i1; ++i) {
             const float p = a.probs[i];
-            if (p >= cutoff) a.keys[pos++] = ((unsigned long long)total_order_key(p) << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+            if (p >= cutoff) atomicAdd(&hmass[total_order_key(p) >> 21], p);
         }
-        int n2 = 1;
-        while (n2 < n0) n2 <<= 1;
-        for (int i = n0 + tid; i < n2; i += kSampThreads) a.keys[i] = 0ull;       // below every real key
         __syncthreads();
-        // bitonic sort, descending: probability first, then ascending index (see header)
-        for (int k = 2; k <= n2; k <<= 1) {
-            for (int jj = k >> 1; jj > 0; jj >>= 1) {
-                for (int i = tid; i < n2; i += kSampThreads) {
-                    const int l = i ^ jj;
-                    if (l > i) {
-                        const unsigned long long x = a.keys[i], y = a.keys[l];
-                        const bool desc = (i & k) == 0;
-                        if (desc ? (x < y) : (x > y)) { a.keys[i] = y; a.keys[l] = x; }
-                    }
-                }
-                __syncthreads();
+        if (tid == 0) {
+            float acc = 0.0f;
+            int b = 2047;
+            for (; b > 0; --b) {
+                acc += hmass[b];
+                if (acc > topp * 1.001f + 1e-6f) break;
             }
+            ired[16] = b > 0 ? b - 1 : 0;                  // one bin of margin
         }
-        for (int i = tid; i < npad; i += kSampThreads) a.sp[i] = (i < n0) ? key_to_float((unsigned)(a.keys[i] >> 32)) : 0.0f;
         __syncthreads();
-        // cumulative probability in sorted order, truncation point, then the cdf walk with r = coin * cumulative
-        wg_exact_prefix(a.sp, blen, 0.0f, xch, in_j, out_j);
-        float cumulative;
-        int last_idx = wg_first_crossing(a.sp, blen, in_j, out_j, topp, red, &cumulative);   // first cum > topp
-        if (last_idx < 0 || last_idx >= n0) last_idx = n0 - 1;                              // (cumulative = total then)
-        __syncthreads();
-        const float r = coin * cumulative;
-        float dummy;
-        int hit = wg_first_crossing(a.sp, blen, in_j, out_j, r, red, &dummy);               // first r < cdf
-        if (hit < 0 || hit > last_idx) hit = last_idx;
+        const unsigned tkey0 = (unsigned)ired[16] << 21;
+        int n0 = 0, hit = 0;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const unsigned tkey = attempt == 0 ? tkey0 : 0u;
+            __syncthreads();
+            // candidates in index order: lane j owns indices [j*blen, (j+1)*blen)
+            int cnt = 0;
+            for (int i = i0; i < i1; ++i) {
+                const float p = a.probs[i];
+                cnt += (p >= cutoff && total_order_key(p) >= tkey) ? 1 : 0;
+            }
+            int inc = cnt;                                 // exclusive scan of the counts over the workgroup
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(inc, d);
+                if (lane >= d) inc += o;
+            }
+            if (lane == 63) ired[wave] = inc;
+            __syncthreads();
+            int off = 0;
+            for (int w = 0; w < wave; ++w) off += ired[w];
+            n0 = 0;
+            for (int w = 0; w < kSampThreads / 64; ++w) n0 += ired[w];
+            int pos = off + inc - cnt;
+            for (int i = i0; i < i1; ++i) {
+                const float p = a.probs[i];
+                if (p >= cutoff && total_order_key(p) >= tkey)
+                    a.keys[pos++] = ((unsigned long long)total_order_key(p) << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+            }
+            int n2 = 1;
+            while (n2 < n0) n2 <<= 1;
+            for (int i = n0 + tid; i < n2; i += kSampThreads) a.keys[i] = 0ull;       // below every real key
+            __syncthreads();
+            // bitonic sort, descending: probability first, then ascending index (see header)
+            for (int k = 2; k <= n2; k <<= 1) {
+                for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                    for (int i = tid; i < n2; i += kSampThreads) {
+                        const int l = i ^ jj;
+                        if (l > i) {
+                            const unsigned long long x = a.keys[i], y = a.keys[l];
+                            const bool desc = (i & k) == 0;
+                            if (desc ? (x < y) : (x > y)) { a.keys[i] = y; a.keys[l] = x; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            for (int i = tid; i < npad; i += kSampThreads) a.sp[i] = (i < n0) ? key_to_float((unsigned)(a.keys[i] >> 32)) : 0.0f;
+            __syncthreads();
+            // cumulative probability in sorted order, truncation point, then the cdf walk with r = coin * cumulative
+            wg_exact_prefix(a.sp, blen, 0.0f, xch, in_j, out_j);
+            float cumulative;
+            int last_idx = wg_first_crossing(a.sp, blen, in_j, out_j, topp, red, &cumulative);   // first cum > topp
+            const bool crossed = last_idx >= 0 && last_idx < n0;
+            if (!crossed && attempt == 0) continue;                                             // prefix too short: sort everything
+            if (!crossed) last_idx = n0 - 1;                                                    // (cumulative = total then)
+            __syncthreads();
+            const float r = coin * cumulative;
+            float dummy;
+            hit = wg_first_crossing(a.sp, blen, in_j, out_j, r, red, &dummy);                   // first r < cdf
+            if (hit < 0 || hit > last_idx) hit = last_idx;
+            break;
+        }
         result = (n0 > 0) ? (int)(0xffffffffu - (unsigned)(a.keys[hit] & 0xffffffffull)) : 0;
     }
     if (tid == 0) {
