@@ -457,7 +457,8 @@ int q3_engine::build_plan() {
 
     split_pos = env_int("Q3_ATT_SPLIT_POS", 256);
     att_stride = (S + 255) & ~255;
-    const int nsl = hd < kSliceW ? 1 : hd / kSliceW;
+    const int slice_w = attn_slice_w(hd, cfg.n_heads, n_cu);
+    const int nsl = hd / slice_w;
     const bool use_att_global = S > att_lds_max;
     HIP_TRY(hipMalloc((void**)&d_att, 4 * (size_t)cfg.n_heads * att_stride));
     HIP_TRY(hipMalloc((void**)&d_att_priv, 4 * (size_t)cfg.n_heads * nsl * att_stride));
@@ -645,7 +646,8 @@ int q3_engine::build_plan() {
         B.aa.att_priv = d_att_priv;
         B.aa.att_stride = att_stride;
         B.grid_y = (unsigned)nsl;
-        B.smem = attn_out_smem_bytes(hd, S);
+        B.aa.slice_w = slice_w;
+        B.smem = attn_out_smem_bytes(hd, S, slice_w);
         if ((rc = set_max_smem((const void*)k_attn_scores, A.smem))) return rc;
         if ((rc = set_max_smem((const void*)k_attn_out, B.smem))) return rc;
         plan_long.push_back(A);
@@ -1144,7 +1146,8 @@ int q3_op_attention(float* xb, float* q, float* key_cache_layer, const float* va
     const bool split = pos >= 256;                       // same rule as the engine's long-context plan
     const bool att_global = split || seq_len > 4096;
     const int att_stride = (int)((seq_len + 255) & ~(size_t)255);
-    const int nsl = head_dim < (size_t)kSliceW ? 1 : (int)(head_dim / kSliceW);
+    const int slice_w = attn_slice_w((int)head_dim, (int)n_heads, 256);
+    const int nsl = (int)head_dim / slice_w;
     DevBuf dpriv, dqout;
     if (att_global && (rc = datt.alloc(4 * n_heads * (size_t)att_stride))) return rc;
     if (split && ((rc = dpriv.alloc(4 * n_heads * nsl * (size_t)att_stride)) || (rc = dqout.alloc(4 * ahd)))) return rc;
@@ -1171,7 +1174,8 @@ int q3_op_attention(float* xb, float* q, float* key_cache_layer, const float* va
         a.att_stride = att_stride;
         a.att_priv = dpriv.as<float>();
         a.q_out = dqout.as<float>();
-        const size_t sm1 = attn_scores_smem_bytes((int)head_dim), sm2 = attn_out_smem_bytes((int)head_dim, (int)seq_len);
+        const size_t sm1 = attn_scores_smem_bytes((int)head_dim), sm2 = attn_out_smem_bytes((int)head_dim, (int)seq_len, slice_w);
+        a.slice_w = slice_w;
         if ((rc = set_max_smem((const void*)k_attn_scores, sm1)) || (rc = set_max_smem((const void*)k_attn_out, sm2))) return rc;
         const unsigned nchunk = (unsigned)((seq_len + attn_tch((int)head_dim) - 1) / attn_tch((int)head_dim));
         hipLaunchKernelGGL(k_attn_scores, dim3((unsigned)n_heads, nchunk), dim3(kWG), sm1, 0, a);

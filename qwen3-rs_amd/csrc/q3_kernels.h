@@ -948,6 +948,7 @@ struct AttnArgs {
     int8_t* pack_q;
     float* pack_s;
     int group;
+    int slice_w;              // k_attn_out: output elements per workgroup (attn_slice_w)
     int k_in_cache;           // batched prefill: row pos of the key cache was already written by k_knorm_rope
 };
 
@@ -1282,17 +1283,24 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a) {
 // k_attn_out: grid (heads, hd/32) -- softmax is recomputed per slice (cheap), the V accumulation is one
 // sequential chain per output element and element slices are independent, so both stay in reference order.
 // ------------------------------------------------------------------------------------------------
-constexpr int kSliceW = 32;    // output elements per k_attn_out workgroup
+// output elements per k_attn_out workgroup: the widest power of two in [8, 32] that still gives every CU a workgroup
+// (n_heads * hd / w >= n_cu): narrow slices stage less V per workgroup, but more than one round over the CUs loses again
+__host__ __device__ inline int attn_slice_w(int hd, int n_heads, int n_cu) {
+    int w = 32;
+    while (w > 8 && (long)n_heads * (hd / w) < (long)n_cu) w >>= 1;
+    return hd < w ? hd : w;
+}
 constexpr int kVChunk = 256;   // timesteps of V staged per LDS round in k_attn_out
+constexpr int kVPad = 4;       // reference-order mode keeps the V chunk transposed, [element][kVChunk + kVPad]: each accumulating
+                               // thread then reads its element's timesteps as float4 (4x fewer LDS reads than one per term)
 constexpr int kPLds = 8192;    // probability rows up to this length live in LDS (32 KiB); longer ones go through HBM/L2
 
 __host__ __device__ inline size_t attn_scores_smem_bytes(int hd) {
     return 4 * ((size_t)hd * 6 + 64 + (size_t)attn_tch(hd) * (hd + kKPad));
 }
-__host__ __device__ inline size_t attn_out_smem_bytes(int hd, int seq_len) {
-    const int w = hd < kSliceW ? hd : kSliceW;
+__host__ __device__ inline size_t attn_out_smem_bytes(int hd, int seq_len, int w) {
     const int pl = ((seq_len + 255) & ~255) <= kPLds ? ((seq_len + 255) & ~255) : 0;
-    return 4 * ((size_t)kVChunk * w + kVChunk + 64 + (size_t)kWaves * w + (size_t)pl);
+    return 4 * ((size_t)(kVChunk + kVPad) * w + kVChunk + 64 + (size_t)kWaves * w + (size_t)pl);
 }
 
 __global__ __launch_bounds__(kWG) void k_attn_scores(const AttnArgs a) {
@@ -1398,9 +1406,9 @@ __global__ __launch_bounds__(kWG) void k_attn_scores(const AttnArgs a) {
 __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int hd = a.hd;
-    const int w = hd < kSliceW ? hd : kSliceW;          // slice width (power of two >= 8)
-    float* vbuf = (float*)smem_raw;                      // [kVChunk][w]
-    float* pbuf = vbuf + kVChunk * w;                    // [kVChunk]
+    const int w = a.slice_w;                             // slice width (power of two >= 8, or hd)
+    float* vbuf = (float*)smem_raw;                      // [kVChunk][w]  (reference order: [w][kVChunk + kVPad])
+    float* pbuf = vbuf + (kVChunk + kVPad) * w;          // [kVChunk]
     float* red = pbuf + kVChunk;                         // [64]
     float* opart = red + 64;                             // [kWaves][w]
     float* p_lds = opart + kWaves * w;                   // [npad] when the row fits (see attn_out_smem_bytes)
@@ -1445,43 +1453,76 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
     v4f o_f = {0.f, 0.f, 0.f, 0.f};
     const int lpt = w >> 2, tpw = 64 / lpt;              // default mode: lanes per timestep / timesteps per wave step
     const int sub = lane / lpt, li = lane % lpt;
-    v4f vreg[8];
-    auto v_issue = [&](int c0) {
+    // two register sets: the V rows of chunks c+1 AND c+2 are in flight while chunk c is folded (one chunk of lookahead
+    // is shorter than an HBM round trip: the fold of 256 timesteps takes ~1 us)
+    struct VRegs { v4f v[8]; };
+    VRegs vra, vrb;
+    auto v_issue = [&](VRegs& R, int c0) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (u < npass) {
                 const int t = min(c0 + r0 + u * rps, np - 1);
-                vreg[u] = *(const v4f*)(vbase + (size_t)t * kvd + 4 * c4);
+                R.v[u] = *(const v4f*)(vbase + (size_t)t * kvd + 4 * c4);
             }
         }
     };
-    auto v_commit = [&](int c0) {
+    constexpr int VLD = kVChunk + kVPad;
+    auto v_commit = [&](const VRegs& R, int c0) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int r = r0 + u * rps;
-            if (u < npass && r < kVChunk && c0 + r < np) *(v4f*)(vbuf + r * w + 4 * c4) = vreg[u];
+            if (a.strict) {
+                // transposed, rows past the context zero-filled: the accumulation below runs in whole float4 steps and
+                // p = +0.0 there, so the padded terms add +0.0 (o + 0.0 == o: o is never -0.0, it starts from +0.0)
+                if (u < npass && r < kVChunk) {
+                    const bool live = c0 + r < np;
+                    const v4f vv = R.v[u];
+                    float* dst = vbuf + (4 * c4) * VLD + r;
+                    dst[0] = live ? vv.x : 0.0f;
+                    dst[VLD] = live ? vv.y : 0.0f;
+                    dst[2 * VLD] = live ? vv.z : 0.0f;
+                    dst[3 * VLD] = live ? vv.w : 0.0f;
+                }
+            } else if (u < npass && r < kVChunk && c0 + r < np) {
+                *(v4f*)(vbuf + r * w + 4 * c4) = R.v[u];
+            }
         }
         for (int t = tid; t < kVChunk; t += kWG) pbuf[t] = (c0 + t < np) ? p[c0 + t] : 0.0f;
     };
-    v_issue(0);
-    for (int c0 = 0; c0 < np; c0 += kVChunk) {
+    auto chunk = [&](VRegs& R, int c0) {
         const int cnt = min(kVChunk, np - c0);
         __syncthreads();                                 // previous chunk fully consumed
-        v_commit(c0);
+        v_commit(R, c0);
         __syncthreads();
-        if (c0 + kVChunk < np) v_issue(c0 + kVChunk);     // next chunk in flight while this one is folded
+        if (c0 + 2 * kVChunk < np) v_issue(R, c0 + 2 * kVChunk);   // this register set is free again: two chunks ahead
         if (a.strict) {
             if (tid < w) {
-                const float* v = vbuf + tid;
-                int t = 0;
-                for (; t + 16 <= cnt; t += 16) {
-                    float vv[16], ww[16];
+                // one sequential chain per output element (layers.rs:406-417); operands arrive as float4 (4 timesteps)
+                // and the next 16 timesteps are in flight while the current 16 are folded
+                const v4f* vr = (const v4f*)(vbuf + tid * VLD);
+                const v4f* pr4 = (const v4f*)pbuf;
+                const int nq8 = ((cnt + 31) >> 5) << 3;          // float4 steps, whole blocks of 8 (zero padded, <= kVChunk/4)
+                auto fold4 = [&](v4f pv, v4f vv) {
+                    float t0 = pv.x * vv.x; o_s = o_s + t0;
+                    t0 = pv.y * vv.y; o_s = o_s + t0;
+                    t0 = pv.z * vv.z; o_s = o_s + t0;
+                    t0 = pv.w * vv.w; o_s = o_s + t0;
+                };
+                v4f av[4], ap[4], bv[4], bp[4];
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) { vv[u] = v[(t + u) * w]; ww[u] = pbuf[t + u]; }
+                for (int u = 0; u < 4; ++u) { av[u] = vr[u]; ap[u] = pr4[u]; }
+                for (int q = 0; q < nq8; q += 8) {
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) { const float pr = ww[u] * vv[u]; o_s = o_s + pr; }
+                    for (int u = 0; u < 4; ++u) { bv[u] = vr[q + 4 + u]; bp[u] = pr4[q + 4 + u]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) fold4(ap[u], av[u]);
+                    if (q + 8 < nq8) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { av[u] = vr[q + 8 + u]; ap[u] = pr4[q + 8 + u]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) fold4(bp[u], bv[u]);
                 }
-                for (; t < cnt; ++t) { const float pr = pbuf[t] * v[t * w]; o_s = o_s + pr; }
             }
         } else {
             for (int tb = wave * tpw; tb < cnt; tb += kWaves * tpw) {
@@ -1496,6 +1537,12 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
                 }
             }
         }
+    };
+    v_issue(vra, 0);
+    if (kVChunk < np) v_issue(vrb, kVChunk);
+    for (int c0 = 0; c0 < np; c0 += 2 * kVChunk) {
+        chunk(vra, c0);
+        if (c0 + kVChunk < np) chunk(vrb, c0 + kVChunk);
     }
     float* out = a.xb + (size_t)h * hd + (size_t)sl * w;
     if (a.strict) {
