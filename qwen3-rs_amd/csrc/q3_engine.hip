@@ -877,7 +877,7 @@ int q3_sampler_set(q3_engine* e, float temperature, float topp, uint64_t rng_see
         HIP_TRY(hipMalloc((void**)&e->d_sp, 4 * (size_t)kSampThreads * blen));
         HIP_TRY(hipMalloc((void**)&e->d_keys, 8 * n2));
     }
-    SamplerState h{rng_seed, temperature, topp};
+    SamplerState h{rng_seed, temperature, topp, {0, 0, 0, 0}};
     HIP_TRY(hipMemcpy(e->d_sampler, &h, sizeof(h), hipMemcpyHostToDevice));
     SampleArgs a{};
     a.logits = e->d_logits;
@@ -903,6 +903,17 @@ int q3_sampler_get_rng(q3_engine* e, uint64_t* rng_state) {
     SamplerState h;
     HIP_TRY(hipMemcpy(&h, e->d_sampler, sizeof(h), hipMemcpyDeviceToHost));
     *rng_state = h.rng;
+    return Q3_OK;
+}
+
+/* developer: correction rounds of the last draw's exact prefix passes (undeclared) */
+int q3_dev_sampler_rounds(q3_engine* e, int32_t* out4) {
+    if (!e || !out4 || !e->d_sampler) return Q3_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    SamplerState h;
+    HIP_TRY(hipMemcpy(&h, e->d_sampler, sizeof(h), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) out4[i] = h.rounds[i];
     return Q3_OK;
 }
 

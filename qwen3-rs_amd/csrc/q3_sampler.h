@@ -21,6 +21,7 @@ struct SamplerState {
     unsigned long long rng;   // sampler.rs:19 rng_state
     float temperature;
     float topp;
+    int rounds[4];            // diagnostics: correction rounds of the last draw's exact prefix passes (softmax sum, cdf / nucleus)
 };
 
 struct SampleArgs {
@@ -64,7 +65,8 @@ __device__ __forceinline__ float wg_scan_incl(float v, float* wtot) {
 // Exact running sums of t[0 .. 1024*blen) (non-negative terms, blen % 4 == 0) folded in index order from `init`:
 // lane j returns in_j = sum before its block [j*blen, (j+1)*blen) and out_j = sum after it, both bit-exact.
 // xch: >= 1024 + 16 floats of LDS.  Every thread of the 1024-thread workgroup must call it.
-__device__ __forceinline__ void wg_exact_prefix(const float* t, int blen, float init, float* xch, float& in_j, float& out_j) {
+__device__ __forceinline__ void wg_exact_prefix(const float* t, int blen, float init, float* xch, float& in_j, float& out_j,
+                                                int* rounds_out = nullptr) {
     const int j = threadIdx.x;
     const v4f* blk = (const v4f*)(t + (size_t)j * blen);
     const int nq = blen >> 2;
@@ -94,7 +96,10 @@ __device__ __forceinline__ void wg_exact_prefix(const float* t, int blen, float 
         const bool ok = (j == 0) || (__float_as_uint(xch[j - 1]) == __float_as_uint(sc));
         g = sc;
         out = out2;
-        if (__syncthreads_and(ok)) break;                   // block 0 is exact by construction; round r fixes block r
+        if (__syncthreads_and(ok)) {                        // block 0 is exact by construction; round r fixes block r
+            if (rounds_out != nullptr && j == 0) *rounds_out = round + 1;
+            break;
+        }
     }
     in_j = g;
     out_j = out;
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a) {
     for (int i = tid; i < npad; i += kSampThreads) a.probs[i] = (i < n) ? q3_expf(a.logits[i] / temperature - m) : 0.0f;
     __syncthreads();
     float in_j, out_j;
-    wg_exact_prefix(a.probs, blen, -0.0f, xch, in_j, out_j);     // Iterator::sum from -0.0
+    wg_exact_prefix(a.probs, blen, -0.0f, xch, in_j, out_j, &ss->rounds[0]);     // Iterator::sum from -0.0
     __syncthreads();
     if (tid == kSampThreads - 1) fred[0] = out_j;
     __syncthreads();
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a) {
     int result;
     if (topp <= 0.0f || topp >= 1.0f) {
         // ---- sample_mult: first i with coin < cdf_i, cdf from 0.0                 sampler.rs:62-71
-        wg_exact_prefix(a.probs, blen, 0.0f, xch, in_j, out_j);
+        wg_exact_prefix(a.probs, blen, 0.0f, xch, in_j, out_j, &ss->rounds[1]);
         float cum;
         const int hit = wg_first_crossing(a.probs, blen, in_j, out_j, coin, red, &cum);
         result = (hit >= 0 && hit < n) ? hit : n - 1;
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a) {
             for (int i = tid; i < npad; i += kSampThreads) a.sp[i] = (i < n0) ? key_to_float((unsigned)(a.keys[i] >> 32)) : 0.0f;
             __syncthreads();
             // cumulative probability in sorted order, truncation point, then the cdf walk with r = coin * cumulative
-            wg_exact_prefix(a.sp, blen, 0.0f, xch, in_j, out_j);
+            wg_exact_prefix(a.sp, blen, 0.0f, xch, in_j, out_j, &ss->rounds[2 + attempt]);
             float cumulative;
             int last_idx = wg_first_crossing(a.sp, blen, in_j, out_j, topp, red, &cumulative);   // first cum > topp
             const bool crossed = last_idx >= 0 && last_idx < n0;
