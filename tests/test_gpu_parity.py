@@ -521,6 +521,23 @@ def test_device_sampler_large_vocab_and_prefill(q3, oracle, tmp_path_factory):
                 assert [first] + rest == want_tokens, f"batched={batched}"
 
 
+def test_engine_runs_an_exported_hf_checkpoint(q3, oracle, tmp_path):
+    """safetensors (F32 + BF16, LoRA adapter) -> export.py -> engine: logits bit-identical to the oracle on that file."""
+    from qwen3_rs_amd import export
+    from test_export import build_model_dir
+    d = str(tmp_path / "hf")
+    build_model_dir(d, tied=True, with_qk_norm=True, lora_rank=4, seed=21)
+    path = str(tmp_path / "exported.bin")
+    export.export_model(d, path, 64)
+    om = oracle.OracleModel(path)
+    with q3.TransformerBuilder(path).build() as t:
+        tok = 5
+        for pos in range(8):
+            a, b = np.array(t.forward(tok, pos), copy=True), om.forward(tok, pos)
+            assert_biteq(a, b, f"pos {pos}")
+            tok = oracle.sample_argmax(b)
+
+
 def test_two_engines_are_independent(q3):
     """Replicas: engines share nothing (own stream, KV cache, scratch, graphs).  Interleaving two engines -- here on one
     device -- gives each exactly the tokens it produces alone."""
