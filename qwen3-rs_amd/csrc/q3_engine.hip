@@ -682,7 +682,7 @@ int q3_engine::enqueue_forward(bool eager, size_t pos) {
 // Sampler::sample on the logits of the forward just enqueued (after k_next has advanced the state)
 int q3_engine::enqueue_sample() {
     if (!sampling) return Q3_OK;
-    hipLaunchKernelGGL(k_sample, dim3(1), dim3(kSampThreads), 0, stream, sargs);
+    hipLaunchKernelGGL(k_sample, dim3(1), dim3(kSampThreads), 4 * kSegFloats, stream, sargs);
     HIP_TRY(hipGetLastError());
     return Q3_OK;
 }
@@ -878,6 +878,8 @@ int q3_sampler_set(q3_engine* e, float temperature, float topp, uint64_t rng_see
         HIP_TRY(hipMalloc((void**)&e->d_keys, 8 * n2));
     }
     SamplerState h{rng_seed, temperature, topp, {0, 0, 0, 0}};
+    int rc = set_max_smem((const void*)k_sample, 4 * kSegFloats);
+    if (rc) return rc;
     HIP_TRY(hipMemcpy(e->d_sampler, &h, sizeof(h), hipMemcpyHostToDevice));
     SampleArgs a{};
     a.logits = e->d_logits;

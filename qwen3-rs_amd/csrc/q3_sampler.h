@@ -137,12 +137,57 @@ __device__ __forceinline__ int wg_first_crossing(const float* t, int blen, float
     return red[1];
 }
 
+// The sequences are far longer than what a lane should re-read from L2 on every correction round, so they are walked in
+// segments of kSegFloats terms staged ONCE in LDS (16 terms per lane): the exact running sum at the end of a segment is
+// the `init` of the next.  visit(seg_base, in_j, out_j) runs after each segment's exact prefix (lane j: terms
+// [seg_base + 16 j, +16)) and returns true to stop early.  Returns the exact running sum after the last segment walked.
+constexpr int kSegBlen = 16;
+constexpr int kSegFloats = kSampThreads * kSegBlen;      // 64 KiB of LDS
+template <class Visit>
+__device__ __forceinline__ float wg_walk_segments(const float* t, int len, float init, float* seg, float* xch, float* carry_lds,
+                                                  int* rounds_out, Visit&& visit) {
+    const int j = threadIdx.x;
+    float carry = init;
+    int rounds_total = 0;
+    for (int base = 0; base < len; base += kSegFloats) {
+        __syncthreads();                                  // the previous segment's readers are done
+#pragma unroll
+        for (int u = 0; u < kSegBlen / 4; ++u) {
+            const int q = j + u * kSampThreads;           // float4 index inside the segment (coalesced)
+            const int i = base + 4 * q;
+            v4f v = {0.f, 0.f, 0.f, 0.f};
+            if (i + 3 < len) v = *(const v4f*)(t + i);
+            else {
+                if (i < len) v.x = t[i];
+                if (i + 1 < len) v.y = t[i + 1];
+                if (i + 2 < len) v.z = t[i + 2];
+            }
+            ((v4f*)seg)[q] = v;
+        }
+        __syncthreads();
+        float in_j, out_j;
+        int r = 0;
+        wg_exact_prefix(seg, kSegBlen, carry, xch, in_j, out_j, j == 0 ? &r : nullptr);
+        rounds_total += r;
+        const bool stop = visit(base, in_j, out_j);
+        __syncthreads();
+        if (j == kSampThreads - 1) *carry_lds = out_j;
+        __syncthreads();
+        carry = *carry_lds;
+        if (stop) break;
+    }
+    if (rounds_out != nullptr && j == 0) *rounds_out = rounds_total;
+    return carry;
+}
+
 __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a) {
     __shared__ float xch[kSampThreads + 16];
     __shared__ int red[4];
     __shared__ float fred[16];
     __shared__ int ired[20];
     __shared__ float hmass[2048];
+    __shared__ float carry_lds;
+    extern __shared__ __attribute__((aligned(16))) float seg[];   // kSegFloats
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     State* st = a.st;
     SamplerState* ss = a.ss;
@@ -162,7 +207,7 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a) {
     if (tid == 0) ss->rng = rs;
     if (discard) return;
 
-    const int n = a.n, blen = a.blen, npad = kSampThreads * blen;
+    const int n = a.n, blen = a.blen;
     // ---- logits / temperature, max                                              sampler.rs:124-126, layers.rs:496
     float m = -__builtin_inff();
     for (int i = tid; i < n; i += kSampThreads) m = fmaxf(m, a.logits[i] / temperature);
@@ -172,14 +217,11 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a) {
     m = fred[0];
     for (int w = 1; w < kSampThreads / 64; ++w) m = fmaxf(m, fred[w]);
     // ---- e = exp(x - max), exact sum in index order, p = e * (1/sum)             layers.rs:497-505
-    for (int i = tid; i < npad; i += kSampThreads) a.probs[i] = (i < n) ? q3_expf(a.logits[i] / temperature - m) : 0.0f;
+    for (int i = tid; i < n; i += kSampThreads) a.probs[i] = q3_expf(a.logits[i] / temperature - m);
     __syncthreads();
-    float in_j, out_j;
-    wg_exact_prefix(a.probs, blen, -0.0f, xch, in_j, out_j, &ss->rounds[0]);     // Iterator::sum from -0.0
-    __syncthreads();
-    if (tid == kSampThreads - 1) fred[0] = out_j;
-    __syncthreads();
-    const float inv = 1.0f / fred[0];
+    const float esum = wg_walk_segments(a.probs, n, -0.0f, seg, xch, &carry_lds, &ss->rounds[0],   // Iterator::sum from -0.0
+                                        [](int, float, float) { return false; });
+    const float inv = 1.0f / esum;
     __syncthreads();
     for (int i = tid; i < n; i += kSampThreads) a.probs[i] = a.probs[i] * inv;
     __syncthreads();
@@ -187,9 +229,13 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a) {
     int result;
     if (topp <= 0.0f || topp >= 1.0f) {
         // ---- sample_mult: first i with coin < cdf_i, cdf from 0.0                 sampler.rs:62-71
-        wg_exact_prefix(a.probs, blen, 0.0f, xch, in_j, out_j, &ss->rounds[1]);
-        float cum;
-        const int hit = wg_first_crossing(a.probs, blen, in_j, out_j, coin, red, &cum);
+        int hit = -1;
+        wg_walk_segments(a.probs, n, 0.0f, seg, xch, &carry_lds, &ss->rounds[1], [&](int base, float in_j, float out_j) {
+            float cum;
+            const int h = wg_first_crossing(seg, kSegBlen, in_j, out_j, coin, red, &cum);
+            if (h >= 0) hit = base + h;
+            return h >= 0;
+        });
         result = (hit >= 0 && hit < n) ? hit : n - 1;
     } else {
         // ---- sample_topp                                                          sampler.rs:74-112
@@ -262,19 +308,29 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a) {
                     __syncthreads();
                 }
             }
-            for (int i = tid; i < npad; i += kSampThreads) a.sp[i] = (i < n0) ? key_to_float((unsigned)(a.keys[i] >> 32)) : 0.0f;
+            for (int i = tid; i < n0; i += kSampThreads) a.sp[i] = key_to_float((unsigned)(a.keys[i] >> 32));
             __syncthreads();
             // cumulative probability in sorted order, truncation point, then the cdf walk with r = coin * cumulative
-            wg_exact_prefix(a.sp, blen, 0.0f, xch, in_j, out_j, &ss->rounds[2 + attempt]);
-            float cumulative;
-            int last_idx = wg_first_crossing(a.sp, blen, in_j, out_j, topp, red, &cumulative);   // first cum > topp
+            int last_idx = -1;
+            float cumulative = 0.0f;
+            const float total = wg_walk_segments(a.sp, n0, 0.0f, seg, xch, &carry_lds, &ss->rounds[2 + attempt],
+                                                 [&](int base, float in_j, float out_j) {
+                float cum;
+                const int h = wg_first_crossing(seg, kSegBlen, in_j, out_j, topp, red, &cum);   // first cum > topp
+                if (h >= 0) { last_idx = base + h; cumulative = cum; }
+                return h >= 0;
+            });
             const bool crossed = last_idx >= 0 && last_idx < n0;
             if (!crossed && attempt == 0) continue;                                             // prefix too short: sort everything
-            if (!crossed) last_idx = n0 - 1;                                                    // (cumulative = total then)
-            __syncthreads();
+            if (!crossed) { last_idx = n0 - 1; cumulative = total; }
             const float r = coin * cumulative;
-            float dummy;
-            hit = wg_first_crossing(a.sp, blen, in_j, out_j, r, red, &dummy);                   // first r < cdf
+            hit = -1;
+            wg_walk_segments(a.sp, last_idx + 1, 0.0f, seg, xch, &carry_lds, nullptr, [&](int base, float in_j, float out_j) {
+                float cum;
+                const int h = wg_first_crossing(seg, kSegBlen, in_j, out_j, r, red, &cum);       // first r < cdf
+                if (h >= 0) hit = base + h;
+                return h >= 0;
+            });
             if (hit < 0 || hit > last_idx) hit = last_idx;
             break;
         }
