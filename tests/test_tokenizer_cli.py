@@ -1,0 +1,179 @@
+"""Tokenizer file writer + runtime (tokenizer_exporter.rs / tokenizer.rs) and the `qwen3` command line."""
+import json
+import math
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_tokenizer_json(d, n_vocab=None):
+    """bytes 0..255 as single-character tokens (GPT-2 mapping), some merges, two special tokens"""
+    from qwen3_rs_amd import tokenizer as tk
+    b2u = {b: ch for ch, b in tk.unicode_to_byte_map().items()}
+    vocab = {b2u[b]: b for b in range(256)}
+    multi = ["he", "ll", "hell", "hello", b2u[32] + "w", "or", b2u[32] + "wor", "ld", b2u[32] + "world", "lo", "é".encode().decode("latin-1").translate({})]
+    multi = multi[:-1] + ["".join(b2u[x] for x in "é".encode())]           # a 2-byte UTF-8 character as one token
+    for t in multi:
+        vocab[t] = len(vocab)
+    merges = ["h e", "l l", "he ll", "hell o", b2u[32] + " w", "o r"]
+    added = [{"id": len(vocab), "content": "<|im_start|>"}, {"id": len(vocab) + 1, "content": "<|im_end|>"}]
+    json.dump({"model": {"vocab": vocab, "merges": merges}, "added_tokens": added}, open(os.path.join(d, "tokenizer.json"), "w"))
+    return len(vocab) + 2
+
+
+def test_unicode_to_byte_map_known_answers(q3):
+    """tokenizer_exporter_test.rs:10-60"""
+    from qwen3_rs_amd import tokenizer as tk
+    assert tk.token_to_bytes("A") == bytes([65]) and tk.token_to_bytes("z") == bytes([122])
+    assert tk.token_to_bytes("!") == bytes([33]) and tk.token_to_bytes("~") == bytes([126])
+    assert tk.token_to_bytes("¡") == bytes([161]) and tk.token_to_bytes("¬") == bytes([172])
+    assert tk.token_to_bytes("®") == bytes([174]) and tk.token_to_bytes("ÿ") == bytes([255])
+    assert tk.token_to_bytes("hello") == bytes([104, 101, 108, 108, 111]) and tk.token_to_bytes("") == b""
+    assert len(tk.token_to_bytes("\0")) == 1 and tk.token_to_bytes("Ā") == bytes([0])      # first unprintable byte
+    assert sorted(tk.unicode_to_byte_map().values()) == list(range(256))
+    # tokenizer_exporter_test.rs:199-207
+    assert tk.merge_rank_score(0) == 0.0
+    assert abs(tk.merge_rank_score(1) + math.log(2)) < 1e-3 and abs(tk.merge_rank_score(10) + 2.397895) < 1e-3
+    assert tk.DEFAULT_SCORE == -1e6
+
+
+def brute_force_encode(vocab, scores, max_len, text):
+    """tokenizer.rs:165-237 with the reference's linear scans"""
+    def lookup(b):
+        for i, t in enumerate(vocab):
+            if t == b:
+                return i
+        return None
+    toks, chars, i = [], list(text), 0
+    while i < len(chars):
+        found = False
+        if chars[i] == "<":
+            end = None
+            for j in range(i + 1, min(len(chars), i + max_len)):
+                if chars[j] == ">":
+                    end = j
+                    break
+            if end is not None:
+                t = lookup("".join(chars[i:end + 1]).encode())
+                if t is not None:
+                    toks.append(t); i = end + 1; found = True
+        if not found:
+            t = lookup(chars[i].encode())
+            if t is not None:
+                toks.append(t)
+            i += 1
+    while True:
+        best, bid, bix = -1e10, None, None
+        for k in range(len(toks) - 1):
+            m = lookup(vocab[toks[k]] + vocab[toks[k + 1]])
+            if m is not None and scores[m] > best:
+                best, bid, bix = scores[m], m, k
+        if bid is None:
+            break
+        toks[bix] = bid
+        del toks[bix + 1]
+    return toks
+
+
+def test_tokenizer_file_roundtrip_and_encode(q3, tmp_path):
+    from qwen3_rs_amd import tokenizer as tk
+    d = str(tmp_path)
+    n = make_tokenizer_json(d)
+    out = tk.export_tokenizer(d, os.path.join(d, "model.bin"), 7, 9)
+    raw = open(out, "rb").read()
+    max_len, bos, eos = struct.unpack_from("<III", raw, 0)
+    assert (bos, eos) == (7, 9) and max_len == len("<|im_start|>")
+    for name, content in ((".template", "<|im_start|>user\n%s<|im_end|>\n<|im_start|>assistant\n"),
+                          (".template.with-system", "<|im_start|>system\n%s<|im_end|>\n<|im_start|>assistant\n")):
+        open(os.path.join(d, "model.bin" + name), "w").write(content)
+    t = tk.Tokenizer(os.path.join(d, "model.bin"), n)
+    assert len(t.vocab) == n and t.vocab[104] == b"h" and t.vocab[n - 2] == b"<|im_start|>"
+    # scores: only tokens whose STRING equals a merge string get -ln(rank+1); here none does -> all default (reference quirk)
+    assert all(s == np.float32(-1e6) for s in t.merge_scores)
+    for text in ["hello world", "hello<|im_start|>hello<|im_end|>", "<notatoken> é!", "a<b", "", "héllo wörld <|im_end|"]:
+        got = t.encode(text)
+        assert got == brute_force_encode(t.vocab, t.merge_scores, t.max_token_length, text), text
+        if "ö" not in text:                                   # a character absent from the vocabulary is skipped (tokenizer.rs:199-202)
+            assert b"".join(t.decode_bytes(i) for i in got) == text.encode()
+    assert t.encode("hello")[0] == t.str_lookup("hello") or len(t.encode("hello")) >= 1
+    assert t.render_prompt(0, None, "hi") == "<|im_start|>user\nhi<|im_end|>\n<|im_start|>assistant\n"
+    assert t.render_prompt(0, "be brief", "hi").startswith("<|im_start|>system\nbe brief\nhi<|im_end|>")
+    assert t.render_prompt(5, "be brief", "hi") == t.render_prompt(0, None, "hi")
+    # a truncated file yields empty trailing tokens with score 0 (tokenizer.rs:55-80)
+    open(out, "wb").write(raw[: len(raw) - 9])
+    t2 = tk.Tokenizer(os.path.join(d, "model.bin"), n)
+    assert t2.vocab[-1] == b"" and len(t2.vocab) == n
+
+
+def test_cli_export_writes_checkpoint_and_tokenizer(q3, tmp_path):
+    from test_export import build_model_dir
+    d = str(tmp_path / "hf")
+    build_model_dir(d, tied=True, with_qk_norm=True, seed=2)
+    make_tokenizer_json(d)
+    out = str(tmp_path / "m.bin")
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "qwen3-rs_amd"))
+    r = subprocess.run([sys.executable, "-m", "qwen3_rs_amd.cli", "export", d, out, "--group-size", "64"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert os.path.getsize(out) > 256 and os.path.exists(out + ".tokenizer")
+    r = subprocess.run([sys.executable, "-m", "qwen3_rs_amd.cli", "export", str(tmp_path / "nope"), out], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "does not exist" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_inference_generate_and_chat_match_the_reference_loops(q3, oracle, tmp_path):
+    """`qwen3 inference` on the device (prefill, forward, sampler) prints what the reference's host loops
+    (generation.rs:9-151) print when driven by the CPU restatement with the same seed."""
+    from qwen3_rs_amd import tokenizer as tk
+    ck = q3.checkpoint
+    d = str(tmp_path)
+    n_vocab = make_tokenizer_json(d)
+    shape = ck.ModelShape(256, 384, 2, 4, 2, n_vocab + (16 - n_vocab % 16) % 16, 96, 64, True, 64)
+    path = os.path.join(d, "model.bin")
+    ck.write_synthetic_checkpoint(path, shape, seed=12)
+    tk.export_tokenizer(d, path, 1, 2)
+    open(path + ".template", "w").write("<|im_start|>%s<|im_end|>")
+    tok = tk.Tokenizer(path, shape.vocab_size)
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "qwen3-rs_amd"))
+
+    def ref_generate(prompt, temperature, topp, seed):
+        om = oracle.OracleModel(path, 40)
+        smp = oracle.Sampler(shape.vocab_size, temperature, topp, seed)
+        ids = tok.encode(prompt)
+        out, token, pos = b"", ids[0], 0
+        while pos < 40:
+            if pos < len(ids) - 1:
+                nxt = ids[pos + 1]
+            else:
+                nxt = smp.sample(om.forward(token, pos))
+                if nxt in (tok.bos_token_id, tok.eos_token_id):
+                    break
+            out += tok.decode_bytes(token)
+            token, pos = nxt, pos + 1
+        return out
+
+    def ref_chat(prompt, temperature, topp, seed):
+        om = oracle.OracleModel(path, 40)
+        smp = oracle.Sampler(shape.vocab_size, temperature, topp, seed)
+        ids, pos, nxt, out = tok.encode(tok.render_prompt(0, None, prompt)), 0, 0, b""
+        for t in ids:
+            nxt = smp.sample(om.forward(t, pos)); pos += 1
+        while pos < 40 and nxt not in (tok.bos_token_id, tok.eos_token_id):
+            out += tok.decode_bytes(nxt)
+            nxt = smp.sample(om.forward(nxt, pos)); pos += 1
+        return out
+
+    for mode, ref in (("generate", ref_generate), ("chat", ref_chat)):
+        for temperature, topp in ((0.0, 0.9), (0.9, 0.8)):
+            r = subprocess.run([sys.executable, "-m", "qwen3_rs_amd.cli", "inference", path, "-m", mode, "-i", "hello world",
+                                "-t", str(temperature), "-p", str(topp), "-s", "77", "-c", "40"], env=env, capture_output=True, timeout=600)
+            assert r.returncode == 0, r.stderr.decode(errors="replace")
+            want = ref("hello world", temperature, topp, 77)
+            assert r.stdout.rstrip(b"\n") == want.rstrip(b"\n") or r.stdout.startswith(want), (mode, temperature, r.stdout, want)
