@@ -436,6 +436,38 @@ def test_batched_prefill_is_sequential_equivalent(q3, shape_name, n_prompt, firs
             t.prefill([1, 2, 10 ** 7], 0, batched=True)
 
 
+@pytest.mark.parametrize("n_heads,n_kv,hd", [(4, 4, 32), (8, 1, 64), (6, 2, 128)])
+def test_batched_paths_other_head_layouts(q3, n_heads, n_kv, hd, tmp_path_factory):
+    """kv_mul 1 (no sharing, head_dim < 64), kv_mul 8 (falls back to the per-head attention kernel; batched prefill then
+    reports UNSUPPORTED and the sequential device loop is used) and kv_mul 3: batched decode / prefill stay bit-identical."""
+    ck = q3.checkpoint
+    dim = 128
+    shape = ck.ModelShape(dim, 256, 2, n_heads, n_kv, 512, 160, hd, True, 64)
+    path = str(tmp_path_factory.mktemp("heads") / "m.bin")
+    ck.write_synthetic_checkpoint(path, shape, seed=n_heads * 100 + n_kv)
+    prompt = ck.iter_prompt_tokens(shape, 9, 45)
+    with q3.TransformerBuilder(path).build() as t:
+        ref = []
+        for i in range(3):
+            t.reset_kv()
+            ref.append(t.generate_greedy(prompt[i], i, 40))
+        t.reset_kv()
+        want_first = t.prefill(prompt, 0)
+        want_k = t.read_state("key")
+        t.batch_init(3)
+        out = t.generate_greedy_batch(prompt[:3], [0, 1, 2], 40)
+        for i in range(3):
+            assert [int(v) for v in out[i]] == ref[i], f"stream {i}"
+        t.reset_kv()
+        try:
+            got_first = t.prefill(prompt, 0, batched=True)
+            assert n_heads // n_kv <= 7
+            assert got_first == want_first
+            assert_biteq(t.read_state("key"), want_k, "key cache after batched prefill")
+        except q3.Q3Error as err:
+            assert err.code == -5 and n_heads // n_kv > 7
+
+
 def test_batched_decode_error_behaviour(q3, tmp_path_factory):
     ck = q3.checkpoint
     path = str(tmp_path_factory.mktemp("bat") / "tiny-g64.bin")
