@@ -15,8 +15,8 @@
 #pragma once
 #include "q3_kernels.h"
 
-// developer ablation of the batched matmul, compile-time only (-DQ3_BABLATE=bits): 1 no B loads, 2 no scale loads,
-// 4 no math, 8 no A loads.  Runtime switches would make the loads conditional and change what is being measured.
+// developer ablation of the batched matmul, compile-time only (-DQ3_BABLATE=bits): 1 no B loads, 4 no term
+// formation / LDS term writes, 8 no A loads, 16 no fold.  Runtime switches would make the loads conditional and change what is being measured.
 #ifdef Q3_BABLATE
 #define Q3_BABL(bit) ((Q3_BABLATE & (bit)) != 0)
 #else
@@ -240,7 +240,9 @@ __global__ __launch_bounds__(kBThreads) void k_bgemm(const BGemmArgs a) {
                     cacc[rt][nt] = c;
                 }
             if (more) issue_group(nxt, ntask, np, k);
-            if (g0 + gg < ng) {
+            if (Q3_BABL(4)) {
+                if (cacc[0][0].x == 0x7fffffff) terms[tid] = 1.0f;      // keep the MFMAs alive
+            } else if (g0 + gg < ng) {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
                     const v4f wsv = *(const v4f*)(wsl + (rt * PG + gg) * 16 + 4 * q);
@@ -264,22 +266,19 @@ __global__ __launch_bounds__(kBThreads) void k_bgemm(const BGemmArgs a) {
         BG_STAMP(3);
         // ---- fold: one (stream, row) accumulator per thread, ascending groups
         const int cnt = min(PG, ng - g0);
-        if (fold_thread) {
+        if (fold_thread && !Q3_BABL(16)) {
+            // all of the phase's terms of this thread's accumulators are requested first (one LDS round trip), then the
+            // RT chains run interleaved; a short last phase folds +0.0 (never written slots are skipped by the select)
+            float v[RT][PG];
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const float* tp = terms + (size_t)rt * PG * NT * 256 + tid;
-                float sacc = acc[rt];
-                int gg = 0;
-                for (; gg + 8 <= cnt; gg += 8) {
-                    float v[8];
+            for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = tp[(size_t)(gg + u) * NT * 256];
+                for (int gg = 0; gg < PG; ++gg) v[rt][gg] = terms[((size_t)rt * PG + gg) * NT * 256 + tid];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) sacc = sacc + v[u];
-                }
-                for (; gg < cnt; ++gg) sacc = sacc + tp[(size_t)gg * NT * 256];
-                acc[rt] = sacc;
-            }
+            for (int gg = 0; gg < PG; ++gg)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    if (gg < cnt) acc[rt] = acc[rt] + v[rt][gg];
         }
         BG_STAMP(4);
         if (more) commit_scales(nxt);                              // scale chunks are only read by the MFMA stage
