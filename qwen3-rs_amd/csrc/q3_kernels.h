@@ -1240,7 +1240,20 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a) {
 #pragma unroll
                     for (int u = 0; u < 16; ++u) { const float p = ww[u] * vv[u]; o_s = o_s + p; }
                 }
-                for (; t < cnt; ++t) { const float p = w[t] * v[t * hd]; o_s = o_s + p; }
+                if (t < cnt) {
+                    // tail of < 16 timesteps as ONE more batch: absent terms are 0 * 0 = +0.0, and o_s + 0.0 == o_s
+                    // (o_s starts from +0.0 and can never be -0.0) -- no per-term LDS round trips
+                    float vv[16], ww[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const bool live = t + u < cnt;
+                        const int tt = live ? t + u : t;
+                        vv[u] = live ? v[tt * hd] : 0.0f;
+                        ww[u] = live ? w[tt] : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) { const float p = ww[u] * vv[u]; o_s = o_s + p; }
+                }
             }
         } else {
             for (int tb = wave * tpw; tb < cnt; tb += kWaves * tpw) {
