@@ -139,6 +139,7 @@ template <int PRO, int EPI, int LPG_T, int RU>
 GemvFn pick_ju(int JU) {
     if (JU == 1) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 1>;
     if (JU == 2) { if constexpr (RU <= 4) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 2>; }
+    if (JU == 3) { if constexpr (RU <= 2) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 3>; }
     if (JU == 4) { if constexpr (RU <= 2) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 4>; }
     return nullptr;
 }
@@ -247,8 +248,22 @@ GemvShape plan_gemv(int units, int n, int G, bool swiglu, int row_align, int n_c
     // launches that stream >= 16 MB are bandwidth- rather than latency-bound: give them a second workgroup per CU
     const size_t launch_bytes = (size_t)units * (swiglu ? 2 : 1) * (size_t)n;
     if (launch_bytes >= (16u << 20) && wg_per_cu < 2) wg_per_cu = 2;
-    const int nj = (n + 1023) / 1024;
-    g.JU = nj == 1 ? 1 : (nj == 2 ? 2 : 4);
+    // chunks (1 KiB wave-loads) per tile row: the largest JU <= 4 that tiles the row exactly (every lane of every load
+    // inside the row: the kernel's clamp-free fast path); rows that are not a whole number of wave-loads (2560, 9728)
+    // take the JU that wastes the fewest clamped loads
+    const int nchunks = n / 16, nj = (n + 1023) / 1024;
+    g.JU = 0;
+    for (int ju = 4; ju >= 1; --ju)
+        if (nchunks % (64 * ju) == 0) { g.JU = ju; break; }
+    if (g.JU == 0) {
+        int best_waste = 1 << 30;
+        for (int ju = 4; ju >= 1; --ju) {
+            const int waste = ((nj + ju - 1) / ju) * ju * 64 - nchunks;
+            if (waste < best_waste) { best_waste = waste; g.JU = ju; }
+        }
+    }
+    const int force_ju = env_int("Q3_GEMV_JU", 0);
+    if (force_ju >= 1 && force_ju <= 4) g.JU = force_ju;
     const int ru_max = 8 / g.JU, ru_min = swiglu ? 2 : 1;
     const int waves = n_cu * wg_per_cu * kWaves;
     int best_ru = ru_min;
