@@ -111,7 +111,8 @@ int q3_prefill(q3_engine* e, const int32_t* tokens, size_t n_tokens, size_t firs
  * the reference's discarded samples (generation.rs:116-123).  temperature 0 restores the argmax path (no coin drawn).
  * All running sums are walked in the reference's order (bit-identical probabilities and tokens); candidates of EQUAL
  * probability in top-p are ordered by ascending token id (the reference's sort_unstable_by leaves that unspecified).
- * q3_forward() is unaffected: it returns logits and leaves sampling to the caller.  Batched decode stays greedy. */
+ * q3_forward() is unaffected: it returns logits and leaves sampling to the caller.  Batched decode has its own
+ * per-stream samplers (q3_batch_sampler_set). */
 int q3_sampler_set(q3_engine* e, float temperature, float topp, uint64_t rng_seed);
 int q3_sampler_get_rng(q3_engine* e, uint64_t* rng_state);
 int q3_forward_sample(q3_engine* e, size_t token, size_t pos, int32_t* next_token);
@@ -158,6 +159,12 @@ int q3_forward_batch(q3_engine* e, const int32_t* tokens, const int32_t* pos, in
  * equals q3_generate_greedy(first_tokens[i], first_pos[i], n_steps) on a fresh engine. */
 int q3_generate_greedy_batch(q3_engine* e, const int32_t* first_tokens, const int32_t* first_pos, int n_streams,
                              size_t n_steps, int32_t* out_tokens);
+
+/* Per-stream Sampler::sample for the batched decode (one sampler per stream: same temperature / top-p, stream i seeded
+ * with rng_seeds[i], [max_streams] values).  With temperature > 0 the tokens of q3_forward_batch (argmax_out) and
+ * q3_generate_greedy_batch are drawn exactly as q3_sampler_set + q3_forward_sample would draw them for that stream alone;
+ * temperature 0 restores the argmax. */
+int q3_batch_sampler_set(q3_engine* e, float temperature, float topp, const uint64_t* rng_seeds);
 
 /* Zero every stream's KV cache. */
 int q3_batch_reset_kv(q3_engine* e);

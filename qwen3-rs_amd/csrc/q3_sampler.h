@@ -35,6 +35,8 @@ struct SampleArgs {
     State* st;
     int32_t* out_tokens;
     int out_cap;
+    // batched decode: workgroup b of the launch samples stream b; element strides between streams (0 for one stream)
+    long long sb_logits, sb_scratch, sb_keys;
 };
 
 __device__ __forceinline__ float key_to_float(unsigned k) {
@@ -180,7 +182,7 @@ __device__ __forceinline__ float wg_walk_segments(const float* t, int len, float
     return carry;
 }
 
-__global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a) {
+__global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a_in) {
     __shared__ float xch[kSampThreads + 16];
     __shared__ int red[4];
     __shared__ float fred[16];
@@ -189,6 +191,17 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a) {
     __shared__ float carry_lds;
     extern __shared__ __attribute__((aligned(16))) float seg[];   // kSegFloats
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    SampleArgs a = a_in;
+    {
+        const size_t sb = blockIdx.x;                  // stream
+        a.logits = a_in.logits + sb * a_in.sb_logits;
+        a.probs = a_in.probs + sb * a_in.sb_scratch;
+        a.sp = a_in.sp + sb * a_in.sb_scratch;
+        a.keys = a_in.keys + sb * a_in.sb_keys;
+        a.ss = a_in.ss + sb;
+        a.st = a_in.st + sb;
+        a.out_tokens = a_in.out_tokens + sb * (size_t)a_in.out_cap;
+    }
     State* st = a.st;
     SamplerState* ss = a.ss;
     const float temperature = ss->temperature, topp = ss->topp;

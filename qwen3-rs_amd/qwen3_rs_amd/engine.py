@@ -18,7 +18,7 @@ _DIST_DIR = os.path.dirname(_PKG_DIR)
 EXPORTED_SYMBOLS = [
     "q3_create", "q3_get_config", "q3_forward", "q3_destroy", "q3_last_error", "q3_forward_argmax",
     "q3_generate_greedy", "q3_prefill", "q3_reset_kv", "q3_read_state", "q3_batch_init", "q3_forward_batch",
-    "q3_generate_greedy_batch", "q3_batch_reset_kv", "q3_batch_read_state", "q3_prefill_batched", "q3_sampler_set", "q3_sampler_get_rng", "q3_forward_sample", "q3_generate_sampled", "q3_profile", "q3_profile_name", "q3_parse_header",
+    "q3_generate_greedy_batch", "q3_batch_reset_kv", "q3_batch_read_state", "q3_prefill_batched", "q3_batch_sampler_set", "q3_sampler_set", "q3_sampler_get_rng", "q3_forward_sample", "q3_generate_sampled", "q3_profile", "q3_profile_name", "q3_parse_header",
     "q3_abi_version", "q3_op_quantize", "q3_op_dequantize", "q3_op_matmul", "q3_op_rmsnorm", "q3_op_softmax",
     "q3_op_swiglu", "q3_op_expf", "q3_op_attention", "q3_op_argmax",
 ]
@@ -97,6 +97,7 @@ def load_library() -> C.CDLL:
     L.q3_batch_init.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
     L.q3_forward_batch.argtypes = [C.c_void_p, i32p, i32p, C.c_int, fp, i32p]
     L.q3_generate_greedy_batch.argtypes = [C.c_void_p, i32p, i32p, C.c_int, sz, i32p]
+    L.q3_batch_sampler_set.argtypes = [C.c_void_p, C.c_float, C.c_float, C.POINTER(C.c_uint64)]
     L.q3_batch_reset_kv.argtypes = [C.c_void_p]
     L.q3_batch_read_state.argtypes = [C.c_void_p, C.c_int, C.c_int, sz, sz, fp]
     L.q3_profile.argtypes = [C.c_void_p, sz, sz, C.c_int, fp, C.POINTER(C.c_int32), C.c_int]
@@ -238,6 +239,11 @@ class Transformer:
         out = np.zeros((n, n_steps), dtype=np.int32)
         self._batch_rc(self._lib.q3_generate_greedy_batch(self._h, tk, ps, n, n_steps, out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out
+
+    def set_batch_sampler(self, temperature: float, topp: float, rng_seeds):
+        """one Sampler per stream (sampler.rs:29-42), stream i seeded with rng_seeds[i]; temperature 0 = greedy"""
+        seeds = (C.c_uint64 * 32)(*([int(s) for s in rng_seeds] + [0] * (32 - len(rng_seeds))))
+        _check(self._lib.q3_batch_sampler_set(self._h, temperature, topp, seeds))
 
     def batch_reset_kv(self):
         _check(self._lib.q3_batch_reset_kv(self._h))

@@ -468,6 +468,34 @@ def test_batched_paths_other_head_layouts(q3, n_heads, n_kv, hd, tmp_path_factor
             assert err.code == -5 and n_heads // n_kv > 7
 
 
+def test_batched_decode_with_per_stream_samplers(q3, tmp_path_factory):
+    """q3_batch_sampler_set: stream i of the batch draws what a single-stream engine with q3_sampler_set(seed_i) draws."""
+    ck = q3.checkpoint
+    shape = ck.SHAPES["small-hd128"]
+    path = str(tmp_path_factory.mktemp("bsamp") / "m.bin")
+    ck.write_synthetic_checkpoint(path, shape, seed=61)
+    toks0, pos0, seeds, steps = [5, 77, 1000, 3], [0, 2, 1, 4], [11, 22, 33, 44], 24
+    for temperature, topp in ((0.8, 0.9), (1.1, 1.0)):
+        with q3.TransformerBuilder(path).build() as t:
+            ref = []
+            for i in range(4):
+                t.reset_kv()
+                t.set_sampler(temperature, topp, seeds[i])
+                ref.append(t.generate_greedy(toks0[i], pos0[i], steps))
+            t.set_sampler(0.0, topp, 0)
+            t.batch_init(4)
+            t.set_batch_sampler(temperature, topp, seeds)
+            out = t.generate_greedy_batch(toks0, pos0, steps)
+            for i in range(4):
+                assert [int(v) for v in out[i]] == ref[i], f"stream {i} T={temperature}"
+            # back to greedy: the argmax path again, no coin drawn
+            t.set_batch_sampler(0.0, topp, seeds)
+            t.batch_reset_kv()
+            g = t.generate_greedy_batch(toks0, pos0, 4)
+            t.reset_kv()
+            assert [int(v) for v in g[0]] == t.generate_greedy(toks0[0], pos0[0], 4)
+
+
 def test_batched_decode_error_behaviour(q3, tmp_path_factory):
     ck = q3.checkpoint
     path = str(tmp_path_factory.mktemp("bat") / "tiny-g64.bin")
