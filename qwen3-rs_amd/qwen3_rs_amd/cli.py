@@ -18,7 +18,7 @@ import time
 
 from . import export as export_mod
 from .engine import TransformerBuilder
-from .tokenizer import Tokenizer, export_tokenizer
+from .tokenizer import Tokenizer, export_templates, export_tokenizer
 
 
 def _emit(tok: Tokenizer, token: int):
@@ -130,7 +130,11 @@ def main(argv=None) -> int:
                 print("wrote", export_tokenizer(a.MODEL_PATH, a.OUTPUT_PATH, info.bos_token_id, info.eos_token_id), file=sys.stderr)
             else:
                 print("tokenizer.json not found: no .tokenizer written", file=sys.stderr)
-            print("chat templates (.template*) are not rendered here; the Rust `qwen3 export` writes them", file=sys.stderr)
+            try:
+                for path in export_templates(a.MODEL_PATH, a.OUTPUT_PATH):
+                    print("wrote", path, file=sys.stderr)
+            except ValueError as err:
+                print(f"no prompt templates written: {err}", file=sys.stderr)
         except (export_mod.ExportError, ValueError, OSError) as err:
             print(f"Error: {err}", file=sys.stderr)
             return 1

@@ -205,3 +205,59 @@ class Tokenizer:
         if pos == 0 and system_prompt is not None:
             return self.system_prompt_template.replace("%s", f"{system_prompt}\n{user_prompt}")
         return self.prompt_template.replace("%s", user_prompt)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Prompt template files (qwen3-export/src/chat_template_exporter.rs): the reference does not render the HF Jinja
+# template; it classifies it (ChatML / DeepSeek markers, :64-86) and writes fixed "%s" patterns (:179-221).
+# ---------------------------------------------------------------------------------------------------------------
+_QWEN3_USER = "<|im_start|>user\n%s<|im_end|>\n<|im_start|>assistant\n"
+_QWEN3_SYSTEM = "<|im_start|>system\n%s<|im_end|>\n" + _QWEN3_USER
+_NO_THINK_QWEN3 = "<think>\n\n</think>\n\n"
+_DEEPSEEK_USER = "<｜User｜>%s<｜Assistant｜>"
+_NO_THINK_DEEPSEEK = "<think>\n</think>"
+
+
+def export_templates(model_dir: str, output_path: str) -> List[str]:
+    """Writes `<output_path>.template[.with-thinking|.with-system|.with-system-and-thinking]`; returns the paths."""
+    cfg_path = os.path.join(model_dir, "tokenizer_config.json")
+    chat_template = None
+    if os.path.exists(cfg_path):
+        try:
+            with open(cfg_path, "r", encoding="utf-8") as f:
+                v = json.load(f).get("chat_template")
+            chat_template = v if isinstance(v, str) else None
+        except ValueError as err:
+            raise ValueError(f"Failed to parse tokenizer config JSON: {err}")
+    if chat_template is None:
+        raise ValueError(f"No chat template found in tokenizer_config.json at {model_dir}")
+    if "<|im_start|>" in chat_template and "<|im_end|>" in chat_template:
+        kind = "qwen3"
+        thinking = "enable_thinking" in chat_template
+        system = "system" in chat_template and "messages[0].role" in chat_template
+    elif "<｜User｜>" in chat_template and "<｜Assistant｜>" in chat_template:
+        kind = "deepseek"
+        thinking, system = "think" in chat_template, "system_prompt" in chat_template
+    else:
+        raise ValueError("Unknown template type, cannot render templates")
+
+    def render(has_system: bool, enable_thinking: bool) -> str:
+        if kind == "qwen3":
+            return (_QWEN3_SYSTEM if has_system else _QWEN3_USER) + ("" if enable_thinking else _NO_THINK_QWEN3)
+        return ("%s" if has_system else "") + _DEEPSEEK_USER + ("" if enable_thinking else _NO_THINK_DEEPSEEK)
+
+    variants = [(".template", False, False)]
+    if thinking:
+        variants.append((".template.with-thinking", False, True))
+    if system:
+        variants.append((".template.with-system", True, False))
+        if thinking:
+            variants.append((".template.with-system-and-thinking", True, True))
+    written = []
+    for suffix, has_system, enable_thinking in variants:
+        path = f"{output_path}{suffix}"
+        with open(path, "w", encoding="utf-8") as f:
+            f.write(render(has_system, enable_thinking))
+        written.append(path)
+    return written
+

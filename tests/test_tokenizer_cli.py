@@ -111,6 +111,31 @@ def test_tokenizer_file_roundtrip_and_encode(q3, tmp_path):
     assert t2.vocab[-1] == b"" and len(t2.vocab) == n
 
 
+def test_template_export_matches_reference_patterns(q3, tmp_path):
+    """chat_template_exporter.rs:64-221: template classification and the fixed %s patterns"""
+    from qwen3_rs_amd import tokenizer as tk
+    d = str(tmp_path)
+    hf = "{%- if messages[0].role == 'system' %}<|im_start|>system...{% endif %}<|im_start|>user<|im_end|>{% if enable_thinking %}"
+    json.dump({"chat_template": hf}, open(os.path.join(d, "tokenizer_config.json"), "w"))
+    paths = tk.export_templates(d, os.path.join(d, "m.bin"))
+    assert [os.path.basename(p) for p in paths] == ["m.bin.template", "m.bin.template.with-thinking", "m.bin.template.with-system",
+                                                   "m.bin.template.with-system-and-thinking"]
+    rd = lambda p: open(p, encoding="utf-8").read()
+    assert rd(paths[0]) == "<|im_start|>user\n%s<|im_end|>\n<|im_start|>assistant\n<think>\n\n</think>\n\n"
+    assert rd(paths[1]) == "<|im_start|>user\n%s<|im_end|>\n<|im_start|>assistant\n"
+    assert rd(paths[2]) == "<|im_start|>system\n%s<|im_end|>\n<|im_start|>user\n%s<|im_end|>\n<|im_start|>assistant\n<think>\n\n</think>\n\n"
+    assert rd(paths[3]).endswith("<|im_start|>assistant\n") and rd(paths[3]).count("%s") == 2
+    json.dump({"chat_template": "{{ system_prompt }}<｜User｜>x<｜Assistant｜>think"}, open(os.path.join(d, "tokenizer_config.json"), "w"))
+    paths = tk.export_templates(d, os.path.join(d, "ds.bin"))
+    assert rd(paths[0]) == "<｜User｜>%s<｜Assistant｜><think>\n</think>" and rd(paths[-1]) == "%s<｜User｜>%s<｜Assistant｜>"
+    json.dump({"chat_template": "plain"}, open(os.path.join(d, "tokenizer_config.json"), "w"))
+    with pytest.raises(ValueError, match="Unknown template type"):
+        tk.export_templates(d, os.path.join(d, "x.bin"))
+    os.remove(os.path.join(d, "tokenizer_config.json"))
+    with pytest.raises(ValueError, match="No chat template found"):
+        tk.export_templates(d, os.path.join(d, "x.bin"))
+
+
 def test_cli_export_writes_checkpoint_and_tokenizer(q3, tmp_path):
     from test_export import build_model_dir
     d = str(tmp_path / "hf")
