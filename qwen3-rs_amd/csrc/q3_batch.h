@@ -525,7 +525,36 @@ __global__ __launch_bounds__(512) void k_attn_gqa(const AttnArgs a0) {
         stage_commit_g(hd, t0, cnt, -1);
         __syncthreads();
         if (c + 1 < nch) stage_issue_g(vbase, t0 + tch, min(tch, np - t0 - tch));
-        if (!kwave) {
+        if (!kwave && hd == 128) {
+            // head_dim 128 (every listed model): the lane's two element chains (lane, lane + 64) advance together and
+            // share the probability reads, which come as float4 -- 2.25 LDS instructions per timestep instead of 4
+            // (measured with tools/lds_probe.hip: these loops cost ~20 cycles per LDS instruction, not per add)
+            const v4f* w4 = (const v4f*)(att + t0);
+            const float* v0 = buf + lane;
+            float o0 = o[0], o1 = o[1];
+            int t = 0;
+            for (; t + 8 <= cnt; t += 8, v0 += 8 * 128) {
+                const v4f pa = w4[t >> 2], pb = w4[(t >> 2) + 1];
+                float a0[8], a1[8];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) { a0[x] = v0[x * 128]; a1[x] = v0[x * 128 + 64]; }
+                const float ww[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+                for (int x = 0; x < 8; ++x) {
+                    const float p0 = ww[x] * a0[x], p1 = ww[x] * a1[x];
+                    o0 = o0 + p0;
+                    o1 = o1 + p1;
+                }
+            }
+            for (; t < cnt; ++t, v0 += 128) {
+                const float wt = att[t0 + t];
+                const float p0 = wt * v0[0], p1 = wt * v0[64];
+                o0 = o0 + p0;
+                o1 = o1 + p1;
+            }
+            o[0] = o0;
+            o[1] = o1;
+        } else if (!kwave) {
             const float* w = att + t0;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
