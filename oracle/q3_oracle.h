@@ -16,6 +16,9 @@
  *     neither be built into oracle/_ref nor imported.  The restatement is cross-checked against
  *     an independent numpy-float32 restatement (oracle/np_oracle.py) and committed fixtures
  *     (tests/golden/), which guards against transcription slips but not a shared misreading.
+ *   - Sampler (sampler.rs): PARITY UNPINNED by the reference as well (no tests there); cross-checked
+ *     against oracle/np_oracle.py (NpSampler) and, for the xorshift64* stream, against an
+ *     arbitrary-precision evaluation of the recurrence.  Top-p ties: see q3o_sample_topp.
  *
  * Arithmetic rules honoured (each cited at the function):  strict left-to-right f32 sums
  * (Rust Iterator::sum), no FMA contraction (build with -ffp-contract=off), no fast-math,
