@@ -219,7 +219,7 @@ struct q3_engine {
     int load(const char* path, uint32_t ctx_len);
     int build_plan();
     int capture();
-    int enqueue_forward(bool eager, size_t pos);
+    int enqueue_forward(bool eager, size_t pos, bool draw = true);
     int set_state(size_t token, size_t pos);
     void release();
 };
@@ -683,7 +683,8 @@ int q3_engine::capture() {
     return Q3_OK;
 }
 
-int q3_engine::enqueue_forward(bool eager, size_t pos) {
+// draw = false: logits only (q3_forward: the caller samples, the device sampler must not consume a coin)
+int q3_engine::enqueue_forward(bool eager, size_t pos, bool draw) {
     const bool lng = (int64_t)pos >= (int64_t)split_pos;
     if (graph_exec && !eager) {
         HIP_TRY(hipGraphLaunch(lng ? graph_long_exec : graph_exec, stream));
@@ -691,7 +692,7 @@ int q3_engine::enqueue_forward(bool eager, size_t pos) {
         for (const Launch& L : (lng ? plan_long : plan)) launch_one(L, this);
         HIP_TRY(hipGetLastError());
     }
-    return enqueue_sample();
+    return draw ? enqueue_sample() : Q3_OK;
 }
 
 // Sampler::sample on the logits of the forward just enqueued (after k_next has advanced the state)
@@ -777,7 +778,7 @@ const float* q3_forward(q3_engine* e, size_t token, size_t pos) {
     if (hipSetDevice(e->device) != hipSuccess) { fail(Q3_ERR_HIP, "hipSetDevice failed"); return nullptr; }
     if (e->set_state(token, pos) != Q3_OK) return nullptr;
     if (dbg) clock_gettime(CLOCK_MONOTONIC, &t1);
-    if (e->enqueue_forward(false, pos) != Q3_OK) return nullptr;
+    if (e->enqueue_forward(false, pos, false) != Q3_OK) return nullptr;
     if (dbg) clock_gettime(CLOCK_MONOTONIC, &t2);
     hipError_t err = hipMemcpyAsync(e->h_logits, e->d_logits, 4 * (size_t)e->cfg.vocab_size, hipMemcpyDeviceToHost, e->stream);
     if (dbg) clock_gettime(CLOCK_MONOTONIC, &t3);

@@ -544,6 +544,8 @@ def test_device_sampler_matches_oracle(q3, oracle, temperature, topp, tmp_path_f
             want.append(nxt)
             tok = nxt
         assert t.sampler_rng_state() == smp.rng_state.value
+        lg = np.array(t.forward(3, 41), copy=True)                      # q3_forward leaves sampling (and the rng) to the caller
+        assert t.sampler_rng_state() == smp.rng_state.value and np.all(np.isfinite(lg))
         # the device-resident loop draws the same sequence
         t.reset_kv()
         t.set_sampler(temperature, topp, seed)
