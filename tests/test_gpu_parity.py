@@ -600,6 +600,63 @@ def test_engine_runs_an_exported_hf_checkpoint(q3, oracle, tmp_path):
             tok = oracle.sample_argmax(b)
 
 
+def _random_shapes(n, seed):
+    """seeded sweep over the supported shape space (group | every inner dimension, head_dim a power of two)"""
+    rng = np.random.default_rng(seed)
+    ck_shapes = []
+    while len(ck_shapes) < n:
+        G = int(rng.choice([16, 32, 64, 128]))
+        hd = int(rng.choice([8, 16, 32, 64, 128]))
+        n_kv = int(rng.choice([1, 2, 3, 4]))
+        kv_mul = int(rng.choice([1, 2, 3, 4, 8]))
+        n_heads = n_kv * kv_mul
+        dim = G * int(rng.integers(1, 6))
+        hidden = G * int(rng.integers(1, 9))
+        if (n_heads * hd) % G or n_heads * hd > 1024:
+            continue
+        vocab = 16 * int(rng.integers(2, 40))
+        L = int(rng.integers(1, 4))
+        seq = int(rng.choice([24, 40, 72]))
+        ck_shapes.append((dim, hidden, L, n_heads, n_kv, vocab, seq, hd, bool(rng.integers(0, 2)), G))
+    return ck_shapes
+
+
+@pytest.mark.parametrize("spec", _random_shapes(16, 2024) + _random_shapes(16, 7), ids=lambda s: "d{}h{}L{}H{}kv{}v{}s{}hd{}t{}g{}".format(*[int(x) for x in s]))
+def test_random_shapes_vs_oracle(q3, oracle, spec, tmp_path):
+    """A seeded sweep of model shapes (odd head layouts, every group size, tied / untied classifier): forward logits
+    bit-identical to the oracle; where the batched paths support the shape, they match the single-stream engine too."""
+    ck = q3.checkpoint
+    shape = ck.ModelShape(*spec)
+    path = str(tmp_path / "m.bin")
+    ck.write_synthetic_checkpoint(path, shape, seed=int(sum(int(x) for x in spec)))
+    om = oracle.OracleModel(path)
+    with q3.TransformerBuilder(path).build() as t:
+        tok, toks = 3 % shape.vocab_size, []
+        for pos in range(10):
+            a, b = np.array(t.forward(tok, pos), copy=True), om.forward(tok, pos)
+            assert_biteq(a, b, f"pos {pos}")
+            tok = oracle.sample_argmax(b)
+            toks.append(tok)
+        t.reset_kv()
+        assert t.generate_greedy(3 % shape.vocab_size, 0, 10) == toks
+        try:
+            t.batch_init(3)
+        except q3.Q3Error as err:
+            assert err.code == -5 and (shape.group_size < 64 or shape.dim % 16 or shape.hidden_dim % 16)
+            return
+        out = t.generate_greedy_batch([3 % shape.vocab_size] * 3, [0, 0, 0], 10)
+        for i in range(3):
+            assert [int(v) for v in out[i]] == toks
+        t.reset_kv()
+        prompt = [3 % shape.vocab_size] + toks[:8]
+        want = t.prefill(prompt, 0)
+        t.reset_kv()
+        try:
+            assert t.prefill(prompt, 0, batched=True) == want == toks[8]
+        except q3.Q3Error as err:
+            assert err.code == -5
+
+
 def test_two_engines_are_independent(q3):
     """Replicas: engines share nothing (own stream, KV cache, scratch, graphs).  Interleaving two engines -- here on one
     device -- gives each exactly the tokens it produces alone."""
