@@ -206,6 +206,8 @@ int q3_op_expf(float* x, size_t n, int device);
 int q3_op_attention(float* xb, float* q, float* key_cache_layer, const float* value_cache_layer,
                     const float* q_norm_w, const float* k_norm_w, size_t pos, size_t seq_len, size_t n_heads,
                     size_t n_kv_heads, size_t head_dim, uint32_t flags, int device);
+/* Sampler::sample with temperature > 0 on caller logits: one draw, *rng_state advanced by one coin   sampler.rs:118-139 */
+int q3_op_sample(const float* logits, size_t n, float temperature, float topp, uint64_t* rng_state, int32_t* index, int device);
 /* Sampler::sample_argmax                                                sampler.rs:57-59 */
 int q3_op_argmax(const float* logits, size_t n, int32_t* index, int device);
 

@@ -1287,6 +1287,43 @@ int q3_dev_bench_gemv(size_t n, size_t d, size_t group_size, int wg_per_cu, int 
     return op_end();
 }
 
+int q3_op_sample(const float* logits, size_t n, float temperature, float topp, uint64_t* rng_state, int32_t* index, int device) {
+    int rc = op_begin(device);
+    if (rc) return rc;
+    if (!logits || !rng_state || !index || n == 0) return fail(Q3_ERR_ARG, "null argument");
+    if (!(temperature > 0.0f)) return fail(Q3_ERR_ARG, "temperature must be positive (0 is q3_op_argmax)");
+    if (!(topp >= 0.0f && topp <= 1.0f)) return fail(Q3_ERR_ARG, "Top-p must be between 0.0 and 1.0");
+    const int blen = 4 * (((int)n + 4095) / 4096);
+    size_t n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    DevBuf dl, dp, ds, dk, dss, dst, dout;
+    SamplerState h{*rng_state, temperature, topp, {0, 0, 0, 0}};
+    State st{};
+    st.step = 1;                                            // "one forward done": the draw is stored in out_tokens[0]
+    if ((rc = dl.upload(logits, 4 * n)) || (rc = dp.alloc(4 * (size_t)kSampThreads * blen)) ||
+        (rc = ds.alloc(4 * (size_t)kSampThreads * blen)) || (rc = dk.alloc(8 * n2)) || (rc = dss.upload(&h, sizeof(h))) ||
+        (rc = dst.upload(&st, sizeof(st))) || (rc = dout.alloc(16)))
+        return rc;
+    if ((rc = set_max_smem((const void*)k_sample, 4 * kSegFloats))) return rc;
+    SampleArgs a{};
+    a.logits = dl.as<float>();
+    a.n = (int)n;
+    a.blen = blen;
+    a.probs = dp.as<float>();
+    a.sp = ds.as<float>();
+    a.keys = dk.as<unsigned long long>();
+    a.ss = dss.as<SamplerState>();
+    a.st = dst.as<State>();
+    a.out_tokens = dout.as<int32_t>();
+    a.out_cap = 4;
+    hipLaunchKernelGGL(k_sample, dim3(1), dim3(kSampThreads), 4 * kSegFloats, 0, a);
+    if ((rc = op_end())) return rc;
+    HIP_TRY(hipMemcpy(&h, dss.p, sizeof(h), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(index, dout.p, 4, hipMemcpyDeviceToHost));
+    *rng_state = h.rng;
+    return Q3_OK;
+}
+
 int q3_op_argmax(const float* logits, size_t n, int32_t* index, int device) {
     int rc = op_begin(device);
     if (rc) return rc;

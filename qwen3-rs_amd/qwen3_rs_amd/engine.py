@@ -20,7 +20,7 @@ EXPORTED_SYMBOLS = [
     "q3_generate_greedy", "q3_prefill", "q3_reset_kv", "q3_read_state", "q3_batch_init", "q3_forward_batch",
     "q3_generate_greedy_batch", "q3_batch_reset_kv", "q3_batch_read_state", "q3_prefill_batched", "q3_batch_sampler_set", "q3_sampler_set", "q3_sampler_get_rng", "q3_forward_sample", "q3_generate_sampled", "q3_profile", "q3_profile_name", "q3_parse_header",
     "q3_abi_version", "q3_op_quantize", "q3_op_dequantize", "q3_op_matmul", "q3_op_rmsnorm", "q3_op_softmax",
-    "q3_op_swiglu", "q3_op_expf", "q3_op_attention", "q3_op_argmax",
+    "q3_op_swiglu", "q3_op_expf", "q3_op_attention", "q3_op_argmax", "q3_op_sample",
 ]
 
 
@@ -113,6 +113,7 @@ def load_library() -> C.CDLL:
     L.q3_op_expf.argtypes = [fp, sz, C.c_int]
     L.q3_op_attention.argtypes = [fp, fp, fp, fp, fp, fp, sz, sz, sz, sz, sz, C.c_uint32, C.c_int]
     L.q3_op_argmax.argtypes = [fp, sz, C.POINTER(C.c_int32), C.c_int]
+    L.q3_op_sample.argtypes = [fp, sz, C.c_float, C.c_float, C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.c_int]
     _lib = L
     return L
 
@@ -400,6 +401,13 @@ class _Ops:
         out = C.c_int32(-1)
         _check(load_library().q3_op_argmax(self._fp(logits), logits.size, C.byref(out), self.device))
         return int(out.value)
+
+    def sample(self, logits, temperature: float, topp: float, rng_state: int):
+        """one Sampler::sample draw on the device; returns (token, new rng_state)"""
+        logits = np.ascontiguousarray(logits, dtype=np.float32)
+        out, st = C.c_int32(-1), C.c_uint64(rng_state)
+        _check(load_library().q3_op_sample(self._fp(logits), logits.size, temperature, topp, C.byref(st), C.byref(out), self.device))
+        return int(out.value), int(st.value)
 
 
 ops = _Ops()

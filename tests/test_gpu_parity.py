@@ -657,6 +657,27 @@ def test_random_shapes_vs_oracle(q3, oracle, spec, tmp_path):
             assert err.code == -5
 
 
+def test_op_sample_random_distributions_vs_oracle(q3, oracle):
+    """q3_op_sample on synthetic logits: peaked, flat, tied, tiny and 152k-entry vocabularies, top-p from 0 to 1 (the
+    histogram preselection and its full-sort fallback, multi-segment exact sums): every draw equals the oracle's."""
+    rng = np.random.default_rng(17)
+    cases = []
+    for n in (2, 17, 1000, 4096, 50000, 151936):
+        for sigma in (0.05, 1.0, 6.0):
+            cases.append((n, sigma))
+    state = 0xC0FFEE
+    for n, sigma in cases:
+        lg = rng.normal(0.0, sigma, n).astype(np.float32)
+        lg[rng.integers(0, n, min(n, 40))] = lg[0]                              # exact ties
+        for temperature, topp in ((1.0, 1.0), (0.7, 0.9), (1.5, 0.3), (0.2, 0.999), (1.0, 0.0)):
+            smp = oracle.Sampler(n, temperature, topp, state)
+            want = smp.sample(lg)
+            got, new_state = q3.ops.sample(lg, temperature, topp, state)
+            assert got == want, (n, sigma, temperature, topp)
+            assert new_state == smp.rng_state.value
+            state = new_state
+
+
 def test_two_engines_are_independent(q3):
     """Replicas: engines share nothing (own stream, KV cache, scratch, graphs).  Interleaving two engines -- here on one
     device -- gives each exactly the tokens it produces alone."""
