@@ -97,6 +97,13 @@ int q3_forward_argmax(q3_engine* e, size_t token, size_t pos, int32_t* next_toke
  * (generation.rs:35) afterwards.  Requires first_pos + n_tokens <= seq_len. */
 int q3_generate_greedy(q3_engine* e, size_t first_token, size_t first_pos, size_t n_tokens, int32_t* out_tokens);
 
+/* The reference's own decode loop on top of q3_forward, in compiled host code: forward -> `logits.to_vec()` ->
+ * Sampler::sample_argmax on the HOST (generation.rs:31-46,153-162; sampler.rs:57-59) -> feed back.  The logits cross
+ * PCIe every token, exactly what a Rust caller of the Transformers::Qwen3Hip shim observes.  *seconds (may be NULL) is
+ * the TokenMetrics interval (generation.rs:198-233): from before the first forward to after the last sample.
+ * Tokens are identical to q3_generate_greedy.  bench.py reports this as `forward_surface`. */
+int q3_host_generate(q3_engine* e, size_t first_token, size_t first_pos, size_t n_tokens, int32_t* out_tokens, double* seconds);
+
 /* The prompt loop of `chat` (handle_user_turn, generation.rs:116-123) kept on the device: every prompt token is
  * forwarded in order at first_pos, first_pos+1, ... (sequential prefill: identical K/V rows and logits to n calls
  * of q3_forward), the per-token sample is discarded, and the argmax after the LAST prompt token -- the first

@@ -924,17 +924,6 @@ int q3_sampler_get_rng(q3_engine* e, uint64_t* rng_state) {
     return Q3_OK;
 }
 
-/* developer: correction rounds of the last draw's exact prefix passes (undeclared) */
-int q3_dev_sampler_rounds(q3_engine* e, int32_t* out4) {
-    if (!e || !out4 || !e->d_sampler) return Q3_ERR_ARG;
-    HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    SamplerState h;
-    HIP_TRY(hipMemcpy(&h, e->d_sampler, sizeof(h), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 4; ++i) out4[i] = h.rounds[i];
-    return Q3_OK;
-}
-
 int q3_forward_sample(q3_engine* e, size_t token, size_t pos, int32_t* next_token) { return q3_forward_argmax(e, token, pos, next_token); }
 
 int q3_generate_sampled(q3_engine* e, size_t first_token, size_t first_pos, size_t n_tokens, int32_t* out_tokens) {
@@ -976,7 +965,14 @@ int q3_profile(q3_engine* e, size_t token, size_t pos, int reps, float* ms, int3
     for (int i = 0; i < cap; ++i) { ms[i] = 0.f; launches[i] = 0; }
     const std::vector<Launch>& P = ((int64_t)pos >= (int64_t)e->split_pos) ? e->plan_long : e->plan;
     const size_t nl = P.size();
-    std::vector<hipEvent_t> ev(2 * F_COUNT);
+    // events are released on every return path (RAII); the replayed launches overwrite x, the logits and KV row `pos`
+    // exactly as a forward(token, pos) would -- callers treat q3_profile as a forward that returns timings
+    struct Events {
+        std::vector<hipEvent_t> ev;
+        ~Events() { for (hipEvent_t x : ev) if (x) (void)hipEventDestroy(x); }
+    } evs;
+    evs.ev.assign(2 * F_COUNT, nullptr);
+    std::vector<hipEvent_t>& ev = evs.ev;
     for (auto& x : ev) HIP_TRY(hipEventCreate(&x));
     for (int r = 0; r < reps; ++r) {
         int rc = e->set_state(token, pos);
@@ -998,8 +994,43 @@ int q3_profile(q3_engine* e, size_t token, size_t pos, int reps, float* ms, int3
             ms[f] += t;
         }
     }
-    for (auto& x : ev) (void)hipEventDestroy(x);
     return F_COUNT;
+}
+
+// The reference's decode loop as its host runs it (generation.rs:31-46,153-162 with temperature 0), in compiled host
+// code on top of q3_forward: forward -> `logits.to_vec()` (a 4*vocab byte copy) -> Sampler::sample_argmax on the host
+// (last maximum under total_cmp, sampler.rs:57-59) -> feed back.  *seconds follows TokenMetrics (generation.rs:198-233):
+// the clock starts before the first forward and stops after the last sample.  This is what a Rust caller of the
+// Transformers::Qwen3Hip shim observes; the logits cross PCIe every token.
+int q3_host_generate(q3_engine* e, size_t first_token, size_t first_pos, size_t n_tokens, int32_t* out_tokens, double* seconds) {
+    g_err[0] = 0;
+    if (!e || (!out_tokens && n_tokens)) return fail(Q3_ERR_ARG, "null argument");
+    if (first_pos + n_tokens > (size_t)e->cfg.seq_len)
+        return fail(Q3_ERR_ARG, "first_pos %zu + n_tokens %zu exceeds seq_len %d", first_pos, n_tokens, e->cfg.seq_len);
+    const size_t V = (size_t)e->cfg.vocab_size;
+    std::vector<float> copy(V);
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    size_t token = first_token;
+    for (size_t k = 0; k < n_tokens; ++k) {
+        const float* lg = q3_forward(e, token, first_pos + k);
+        if (!lg) return Q3_ERR_HIP;
+        memcpy(copy.data(), lg, 4 * V);                                   // generation.rs:160  logits.to_vec()
+        size_t best = 0;
+        int32_t best_key = INT32_MIN;
+        bool have = false;
+        for (size_t i = 0; i < V; ++i) {                                  // Iterator::max_by(total_cmp): last maximum
+            int32_t b;
+            memcpy(&b, &copy[i], 4);
+            const int32_t key = b < 0 ? (b ^ 0x7fffffff) : b;
+            if (!have || key >= best_key) { best_key = key; best = i; have = true; }
+        }
+        out_tokens[k] = (int32_t)best;
+        token = best;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (seconds) *seconds = (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9;
+    return Q3_OK;
 }
 
 }  // extern "C"

@@ -167,24 +167,35 @@ def _tensor_rng(seed: int, tensor_idx: int, item: int, chunk: int) -> np.random.
 
 
 def _synth_chunk(seed: int, tidx: int, item: int, chunk: int, n: int, sigma: float, group: int):
+    """One chunk of a synthetic tensor: N(0, sigma^2) f32 pushed through quantize_q80's rule (model_exporter.rs:119-136;
+    same arithmetic as quantize_q80 above without its max-error pass)."""
     w = _tensor_rng(seed, tidx, item, chunk).standard_normal(n, dtype=np.float32)
     w *= np.float32(sigma)
-    q, s, _ = quantize_q80(w, group)
-    return q, s
+    g = w.reshape(-1, group)
+    gmax = np.max(np.abs(g), axis=1)
+    scale = np.where(gmax > 0, gmax / np.float32(127.0), np.float32(1.0)).astype(np.float32)
+    np.divide(g, scale[:, None], out=g)
+    np.rint(g, out=g)
+    np.clip(g, -127.0, 127.0, out=g)
+    return g.astype(np.int8).reshape(-1), scale
 
 
 def write_synthetic_checkpoint(path: str, shape: ModelShape, seed: int = 1234, *, chunk_rows: int = 4096,
                                workers: int | None = None, sparse_zero_groups: bool = False) -> int:
     """Write a synthetic checkpoint of `shape` (i.i.d. N(0, sigma^2) f32 rows pushed
     through the exporter rule quantize_q80, norm weights 1 + N(0, 0.1^2)).  Deterministic in (shape, seed)
-    and independent of chunking/threads.  Returns the number of bytes written.
+    and independent of the worker count (the rng is keyed by tensor / item / chunk).  Returns the number of bytes written.
 
     sparse_zero_groups: zero a few weight groups so the exporter's scale-1.0 rule for all-zero groups
     (model_exporter.rs:122) is exercised by parity tests.
     """
     g = shape.group_size
-    workers = workers or min(8, os.cpu_count() or 1)
+    workers = workers or min(32, os.cpu_count() or 1)
     tmp = path + ".tmp"
+    # every (tensor, item) in file order; chunk jobs of several items are in flight at once so that tensors with few
+    # chunks per item (3 for a 12288 x 4096 matrix) still keep every worker busy
+    items = [(tidx, name, item, rows, cols)
+             for tidx, (name, cnt, rows, cols) in enumerate(shape.quantized_tensors()) for item in range(cnt)]
     with open(tmp, "wb") as f:
         f.write(header_bytes(shape))
         for ni, (_, count) in enumerate(shape.norm_tensors()):
@@ -192,30 +203,37 @@ def write_synthetic_checkpoint(path: str, shape: ModelShape, seed: int = 1234, *
             w = (1.0 + 0.1 * rng.standard_normal(count, dtype=np.float32)).astype(np.float32)
             f.write(w.tobytes())
         with ThreadPoolExecutor(max_workers=workers) as pool:
-            for tidx, (name, cnt, rows, cols) in enumerate(shape.quantized_tensors()):
+            def submit(k):
+                tidx, name, item, rows, cols = items[k]
                 sigma = 0.05 if name in ("embed_tokens", "lm_head") else float(cols) ** -0.5
-                for item in range(cnt):
-                    jobs = []
-                    for ci, r0 in enumerate(range(0, rows, chunk_rows)):
-                        nr = min(chunk_rows, rows - r0)
-                        jobs.append(pool.submit(_synth_chunk, seed, tidx, item, ci, nr * cols, sigma, g))
-                    qs, ss = [], []
-                    for j in jobs:
-                        q, s = j.result()
-                        qs.append(q)
-                        ss.append(s)
-                    if sparse_zero_groups and name not in ("embed_tokens",):
-                        # zero group 1 of the first row: scale must be written as 1.0
-                        q0 = qs[0].copy()
-                        s0 = ss[0].copy()
-                        if q0.size >= 2 * g:
-                            q0[g:2 * g] = 0
-                            s0[1] = 1.0
-                        qs[0], ss[0] = q0, s0
-                    for q in qs:
-                        f.write(q.tobytes())
-                    for s in ss:
-                        f.write(s.astype("<f4").tobytes())
+                return [pool.submit(_synth_chunk, seed, tidx, item, ci, min(chunk_rows, rows - r0) * cols, sigma, g)
+                        for ci, r0 in enumerate(range(0, rows, chunk_rows))]
+            pending, nxt, in_flight = {}, 0, 0
+            for k in range(len(items)):
+                while nxt < len(items) and (in_flight < 2 * workers or nxt <= k):
+                    pending[nxt] = submit(nxt)
+                    in_flight += len(pending[nxt])
+                    nxt += 1
+                jobs = pending.pop(k)
+                in_flight -= len(jobs)
+                name = items[k][1]
+                qs, ss = [], []
+                for j in jobs:
+                    q, sc = j.result()
+                    qs.append(q)
+                    ss.append(sc)
+                if sparse_zero_groups and name not in ("embed_tokens",):
+                    # zero group 1 of the first row: scale must be written as 1.0
+                    q0 = qs[0].copy()
+                    s0 = ss[0].copy()
+                    if q0.size >= 2 * g:
+                        q0[g:2 * g] = 0
+                        s0[1] = 1.0
+                    qs[0], ss[0] = q0, s0
+                for q in qs:
+                    f.write(q.tobytes())
+                for sc in ss:
+                    f.write(sc.astype("<f4").tobytes())
         n = f.tell()
     os.replace(tmp, path)
     assert n == shape.file_size(), (n, shape.file_size())

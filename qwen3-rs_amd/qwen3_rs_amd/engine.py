@@ -17,7 +17,7 @@ _DIST_DIR = os.path.dirname(_PKG_DIR)
 # every symbol include/qwen3_hip.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = [
     "q3_create", "q3_get_config", "q3_forward", "q3_destroy", "q3_last_error", "q3_forward_argmax",
-    "q3_generate_greedy", "q3_prefill", "q3_reset_kv", "q3_read_state", "q3_batch_init", "q3_forward_batch",
+    "q3_generate_greedy", "q3_host_generate", "q3_prefill", "q3_reset_kv", "q3_read_state", "q3_batch_init", "q3_forward_batch",
     "q3_generate_greedy_batch", "q3_batch_reset_kv", "q3_batch_read_state", "q3_prefill_batched", "q3_batch_sampler_set", "q3_sampler_set", "q3_sampler_get_rng", "q3_forward_sample", "q3_generate_sampled", "q3_profile", "q3_profile_name", "q3_parse_header",
     "q3_abi_version", "q3_op_quantize", "q3_op_dequantize", "q3_op_matmul", "q3_op_rmsnorm", "q3_op_softmax",
     "q3_op_swiglu", "q3_op_expf", "q3_op_attention", "q3_op_argmax", "q3_op_sample",
@@ -85,6 +85,7 @@ def load_library() -> C.CDLL:
     L.q3_destroy.restype = None
     L.q3_forward_argmax.argtypes = [C.c_void_p, sz, sz, C.POINTER(C.c_int32)]
     L.q3_generate_greedy.argtypes = [C.c_void_p, sz, sz, sz, C.POINTER(C.c_int32)]
+    L.q3_host_generate.argtypes = [C.c_void_p, sz, sz, sz, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.q3_prefill.argtypes = [C.c_void_p, C.POINTER(C.c_int32), sz, sz, C.POINTER(C.c_int32)]
     L.q3_prefill_batched.argtypes = [C.c_void_p, C.POINTER(C.c_int32), sz, sz, C.POINTER(C.c_int32)]
     L.q3_sampler_set.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_uint64]
@@ -176,6 +177,17 @@ class Transformer:
             raise IndexError(self._lib.q3_last_error().decode(errors="replace"))
         _check(rc)
         return [int(buf[i]) for i in range(n_tokens)]
+
+    def host_generate(self, first_token: int, first_pos: int, n_tokens: int) -> Tuple[List[int], float]:
+        """The reference's decode loop in compiled host code on top of forward(): logits egress + host argmax per
+        token (generation.rs:153-162).  Returns (tokens, TokenMetrics seconds)."""
+        buf = (C.c_int32 * max(1, n_tokens))()
+        secs = C.c_double(0.0)
+        rc = self._lib.q3_host_generate(self._h, first_token, first_pos, n_tokens, buf, C.byref(secs))
+        if rc == -3:
+            raise IndexError(self._lib.q3_last_error().decode(errors="replace"))
+        _check(rc)
+        return [int(buf[i]) for i in range(n_tokens)], float(secs.value)
 
     def prefill(self, tokens, first_pos: int = 0, batched: bool = False) -> int:
         """chat-mode prompt loop on the device (generation.rs:116-123); returns the first generated token.

@@ -155,3 +155,54 @@ def test_replica_aggregation_two_ranks_gloo():
     for r in (0, 1):
         tokens, seconds = res[r]
         assert tokens == 201 and abs(seconds - 0.75) < 1e-9
+
+
+def test_bench_gpus2_spawns_two_replica_workers_stub_engine():
+    """`python bench.py --gpus 2` must itself start two worker processes (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE set,
+    gloo barrier + max/sum aggregation) BEFORE anything touches HIP, and print ONE line with n_gpus 2.  The workers use
+    the launcher's host stub here (no GPU in this container); on the GPU box the same launcher starts real engines."""
+    import json
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2",
+                        "--stub-engine"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 12 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["replicas"] == 2
+    # whole-job value: 2 replicas x 12 tokens over the slowest replica's time
+    assert abs(d["value"] - 24 / (d["ms_per_step"] * 12 / 1e3)) / d["value"] < 1e-3
+    assert "_tokens" not in d
+
+
+def test_bench_cpu_leg_compares_equal_length_prefixes(oracle, tmp_ckpt_dir):
+    """The oracle leg compares min(len(cpu), len(gpu)) tokens (a --steps below the CPU sample must not read as a
+    mismatch) and reports both the all-core and the one-thread figure; a wrong token flips the verdict."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from qwen3_rs_amd import checkpoint as ck
+    sh = ck.SHAPES["tiny-g64"]
+    path = os.path.join(tmp_ckpt_dir, "bench_tiny.bin")
+    ck.ensure_synthetic_checkpoint(path, sh, seed=5)
+    m = oracle.OracleModel(path, 64)
+    tok, toks = 3, []
+    for k in range(20):
+        tok = oracle.sample_argmax(m.forward(tok, 7 + k))
+        toks.append(tok)
+    m.close()
+    for n in (5, 20):
+        cb, ok = bench.cpu_baseline(path, 64, 3, 7, toks[:n], max_tokens=12, budget_s=5, one_thread_budget_s=2)
+        assert ok and cb["tokens_match_gpu"] and cb["tokens_compared"] == min(n, 12)
+        assert cb["one_thread"]["cores"] == 1 and cb["one_thread"]["value"] > 0 and cb["value"] > 0
+    bad = list(toks)
+    bad[2] = (bad[2] + 1) % sh.vocab_size
+    cb, ok = bench.cpu_baseline(path, 64, 3, 7, bad, max_tokens=12, budget_s=5, one_thread_budget_s=2)
+    assert not ok and not cb["tokens_match_gpu"]
+
+
+def test_batch_entry_points_reject_prefill_only_context(q3):
+    """q3_batch_reset_kv / q3_batch_read_state on an engine without q3_batch_init must fail cleanly
+    (null engine here: no GPU in the CPU suite; the has_kv guard itself is exercised on the GPU box)."""
+    L = q3.load_library()
+    assert L.q3_batch_reset_kv(None) == -3

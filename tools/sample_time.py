@@ -14,6 +14,4 @@ with q3.TransformerBuilder(path).with_ctx_length(1024).build() as t:
         t.set_sampler(temp, topp, 1234)
         t.reset_kv()
         t0 = time.perf_counter(); toks = t.generate_greedy(5, 7, 64); dt = time.perf_counter() - t0
-        r = (C.c_int32 * 4)(); t._lib.q3_dev_sampler_rounds.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
-        if temp > 0: t._lib.q3_dev_sampler_rounds(t._h, r)
-        print(f"{name} temperature {temp} topp {topp}: {dt/64*1e6:9.1f} us/token  first tokens {toks[:4]}  rounds {list(r)}", flush=True)
+        print(f"{name} temperature {temp} topp {topp}: {dt/64*1e6:9.1f} us/token  first tokens {toks[:4]}", flush=True)
