@@ -124,7 +124,8 @@ typedef void (*GemvFn)(const GemvArgs);
 struct Launch {
     Family fam;
     bool is_attn = false, is_next = false;
-    int attn_kind = 0;     // 0: single-kernel attention, 1: k_attn_scores, 2: k_attn_out (long-context split)
+    int attn_kind = 0;     // 0: single-kernel attention, 1: k_attn_scores, 2: k_attn_out (long-context split),
+                           // 3: k_attn_short (pos < 256, head_dim 64/128: K rows in registers, no LDS staging)
     unsigned grid_y = 1;
     GemvFn fn = nullptr;
     GemvArgs ga{};
@@ -134,19 +135,27 @@ struct Launch {
 };
 
 // tile shapes instantiated: group 64 (every listed model) gets the full set, other group sizes a
-// single-row-run fallback (RU = 1, or 2 for SwiGLU).
-template <int PRO, int EPI, int LPG_T, int RU>
+// single-row-run fallback (RU = 1, or 2 for SwiGLU).  FIN = 1 (register fold of the group terms, latency-bound launches)
+// exists for group 64 with RU <= 2.
+template <int PRO, int EPI, int LPG_T, int RU, int FIN = 0>
 GemvFn pick_ju(int JU) {
-    if (JU == 1) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 1>;
-    if (JU == 2) { if constexpr (RU <= 4) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 2>; }
-    if (JU == 3) { if constexpr (RU <= 2) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 3>; }
-    if (JU == 4) { if constexpr (RU <= 2) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 4>; }
+    if (JU == 1) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 1, FIN>;
+    if (JU == 2) { if constexpr (RU <= 4) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 2, FIN>; }
+    if (JU == 3) { if constexpr (RU <= 2) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 3, FIN>; }
+    if (JU == 4) { if constexpr (RU <= 2) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 4, FIN>; }
     return nullptr;
 }
 template <int PRO, int EPI>
-GemvFn pick(int G, int RU, int JU) {
+GemvFn pick(int G, int RU, int JU, int FIN = 0) {
     constexpr bool sw = (EPI == EPI_SWIGLU);
     if (G == 64) {
+        if constexpr (EPI != EPI_LOGITS) {
+            if (FIN) {
+                if (RU == 2) return pick_ju<PRO, EPI, 4, 2, 1>(JU);
+                if constexpr (!sw) { if (RU == 1) return pick_ju<PRO, EPI, 4, 1, 1>(JU); }
+                return nullptr;
+            }
+        }
         if (RU == 8) return pick_ju<PRO, EPI, 4, 8>(JU);
         if (RU == 4) return pick_ju<PRO, EPI, 4, 4>(JU);
         if (RU == 2) return pick_ju<PRO, EPI, 4, 2>(JU);
@@ -230,6 +239,10 @@ void launch_one(const Launch& L, q3_engine* e) {
     if (L.is_attn) {
         if (L.attn_kind == 1) hipLaunchKernelGGL(k_attn_scores, dim3(L.grid, L.grid_y), dim3(kWG), L.smem, e->stream, L.aa);
         else if (L.attn_kind == 2) hipLaunchKernelGGL(k_attn_out, dim3(L.grid, L.grid_y), dim3(kWG), L.smem, e->stream, L.aa);
+        else if (L.attn_kind == 3) {
+            if (L.aa.hd == 128) hipLaunchKernelGGL(k_attn_short<128>, dim3(L.grid), dim3(kWG), 0, e->stream, L.aa);
+            else hipLaunchKernelGGL(k_attn_short<64>, dim3(L.grid), dim3(kWG), 0, e->stream, L.aa);
+        }
         else hipLaunchKernelGGL(k_attn, dim3(L.grid), dim3(kWG), L.smem, e->stream, L.aa);
     } else if (L.is_next) {
         hipLaunchKernelGGL(k_next, dim3(1), dim3(kWG), 0, e->stream, e->d_state, e->d_argmax_slots, e->n_argmax_slots,
@@ -242,9 +255,10 @@ void launch_one(const Launch& L, q3_engine* e) {
 // Tile shape + grid for one GEMV launch.  units = output rows (SwiGLU: hidden units, each 2 weight rows).
 // JU follows the row length (1 KiB chunks per row); RU is the largest row count per wave batch that keeps
 // every wave of the grid busy and minimises max rows per wave; larger kernels grid-stride over batches.
-struct GemvShape { int RU, JU; unsigned grid; };
-GemvShape plan_gemv(int units, int n, int G, bool swiglu, int row_align, int n_cu, int wg_per_cu) {
+struct GemvShape { int RU, JU; unsigned grid; int FIN; };
+GemvShape plan_gemv(int units, int n, int G, bool swiglu, int row_align, int n_cu, int wg_per_cu, bool allow_fin = true) {
     GemvShape g;
+    g.FIN = 0;
     // launches that stream >= 16 MB are bandwidth- rather than latency-bound: give them a second workgroup per CU
     const size_t launch_bytes = (size_t)units * (swiglu ? 2 : 1) * (size_t)n;
     if (launch_bytes >= (16u << 20) && wg_per_cu < 2) wg_per_cu = 2;
@@ -266,6 +280,19 @@ GemvShape plan_gemv(int units, int n, int G, bool swiglu, int row_align, int n_c
     if (force_ju >= 1 && force_ju <= 4) g.JU = force_ju;
     const int ru_max = 8 / g.JU, ru_min = swiglu ? 2 : 1;
     const int waves = n_cu * wg_per_cu * kWaves;
+    // latency-bound launches whose rows are a whole number of tiles: register fold of the group terms (k_gemv FIN = 1),
+    // one or two rows per wave batch
+    if (allow_fin && env_int("Q3_GEMV_FIN", 1) && G == 64 && nchunks % (64 * g.JU) == 0 && launch_bytes < (16u << 20)) {
+        g.FIN = 1;
+        const bool two = swiglu || ((units + waves - 1) / waves >= 2 && (row_align <= 1 || row_align % 2 == 0) && g.JU <= 4);
+        g.RU = two ? 2 : 1;
+        const int hu = swiglu ? 1 : g.RU;
+        const long nb = (units + hu - 1) / hu;
+        long grid = (nb + kWaves - 1) / kWaves;
+        if (grid > (long)n_cu * wg_per_cu) grid = (long)n_cu * wg_per_cu;
+        g.grid = (unsigned)(grid < 1 ? 1 : grid);
+        return g;
+    }
     int best_ru = ru_min;
     long best_cost = -1;
     for (int ru = ru_max; ru >= ru_min; ru >>= 1) {
@@ -517,9 +544,9 @@ int q3_engine::build_plan() {
                 a.emb_q = tok.q;
                 a.emb_s = tok.s;
                 a.x_out = d_x;
-                Ln.fn = pick<PRO_EMBED_NORM, EPI_QKV>(G, gs.RU, gs.JU);
+                Ln.fn = pick<PRO_EMBED_NORM, EPI_QKV>(G, gs.RU, gs.JU, gs.FIN);
             } else {
-                Ln.fn = pick<PRO_NORM, EPI_QKV>(G, gs.RU, gs.JU);
+                Ln.fn = pick<PRO_NORM, EPI_QKV>(G, gs.RU, gs.JU, gs.FIN);
             }
             a.vr = gs.RU;
             Ln.grid = gs.grid;
@@ -558,6 +585,8 @@ int q3_engine::build_plan() {
             Ln.grid = (unsigned)cfg.n_heads;
             Ln.smem = attn_smem_bytes(hd, use_att_global ? 0 : S);
             if ((rc = set_max_smem((const void*)k_attn, Ln.smem))) return rc;
+            // the short plan only ever runs at pos < split_pos
+            if ((hd == 64 || hd == 128) && split_pos <= kShortMaxT && env_int("Q3_ATT_SHORT", 1)) Ln.attn_kind = 3;
             plan.push_back(Ln);
         }
         {   // xq = quantize(xb); x += Wo xq                                      qwen3.rs:152-156
@@ -568,7 +597,7 @@ int q3_engine::build_plan() {
             a.total_rows = dim;
             a.in = d_xb;
             const GemvShape gs = plan_gemv(dim, ahd, G, false, 1, n_cu, small_cap);
-            Ln.fn = pick<PRO_QUANT, EPI_RESID>(G, gs.RU, gs.JU);
+            Ln.fn = pick<PRO_QUANT, EPI_RESID>(G, gs.RU, gs.JU, gs.FIN);
             a.vr = gs.RU;
             Ln.grid = gs.grid;
             Ln.smem = gemv_smem_bytes(ahd, G, a.vr, false);
@@ -588,7 +617,7 @@ int q3_engine::build_plan() {
             a.norm_w = rms_ffn + (size_t)l * dim;
             a.in = d_x;
             const GemvShape gs = plan_gemv(H, dim, G, true, 1, n_cu, small_cap);
-            Ln.fn = pick<PRO_NORM, EPI_SWIGLU>(G, gs.RU, gs.JU);
+            Ln.fn = pick<PRO_NORM, EPI_SWIGLU>(G, gs.RU, gs.JU, gs.FIN);
             a.vr = gs.RU;
             Ln.grid = gs.grid;
             Ln.smem = gemv_smem_bytes(dim, G, a.vr, true);
@@ -606,7 +635,7 @@ int q3_engine::build_plan() {
             a.total_rows = dim;
             a.in = d_hb;
             const GemvShape gs = plan_gemv(dim, H, G, false, 1, n_cu, small_cap);
-            Ln.fn = pick<PRO_QUANT, EPI_RESID>(G, gs.RU, gs.JU);
+            Ln.fn = pick<PRO_QUANT, EPI_RESID>(G, gs.RU, gs.JU, gs.FIN);
             a.vr = gs.RU;
             Ln.grid = gs.grid;
             Ln.smem = gemv_smem_bytes(H, G, a.vr, false);
@@ -626,7 +655,7 @@ int q3_engine::build_plan() {
         a.norm_w = rms_final;
         a.in = d_x;
         a.tap_out = d_tap;
-        const GemvShape gs = plan_gemv(V, dim, G, false, 1, n_cu, big_cap);
+        const GemvShape gs = plan_gemv(V, dim, G, false, 1, n_cu, big_cap, false);
         n_argmax_slots = (int)gs.grid;
         HIP_TRY(hipMalloc((void**)&d_argmax_slots, 8 * (size_t)n_argmax_slots));
         HIP_TRY(hipMemset(d_argmax_slots, 0, 8 * (size_t)n_argmax_slots));
@@ -1120,7 +1149,7 @@ int q3_op_matmul(float* xout, const int8_t* xq, const float* xs, const int8_t* w
     a.vr = gs.RU;
     const unsigned grid = gs.grid;
     const size_t smem = gemv_smem_bytes((int)n, (int)group_size, a.vr, false);
-    GemvFn fn = pick<PRO_PREQ, EPI_STORE>((int)group_size, gs.RU, gs.JU);
+    GemvFn fn = pick<PRO_PREQ, EPI_STORE>((int)group_size, gs.RU, gs.JU, gs.FIN);
     if (!fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel for tile %dx%d", gs.RU, gs.JU);
     if ((rc = set_max_smem((const void*)fn, smem))) return rc;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kWG), smem, 0, a);
@@ -1242,6 +1271,9 @@ int q3_op_attention(float* xb, float* q, float* key_cache_layer, const float* va
         hipLaunchKernelGGL(k_attn_out, dim3((unsigned)n_heads, (unsigned)nsl), dim3(kWG), sm2, 0, a);
         if ((rc = op_end())) return rc;
         HIP_TRY(hipMemcpy(dq.p, dqout.p, 4 * ahd, hipMemcpyDeviceToDevice));
+    } else if ((head_dim == 64 || head_dim == 128) && env_int("Q3_ATT_SHORT", 1)) {
+        if (head_dim == 128) hipLaunchKernelGGL(k_attn_short<128>, dim3((unsigned)n_heads), dim3(kWG), 0, 0, a);
+        else hipLaunchKernelGGL(k_attn_short<64>, dim3((unsigned)n_heads), dim3(kWG), 0, 0, a);
     } else {
         const size_t smem = attn_smem_bytes((int)head_dim, att_global ? 0 : (int)seq_len);
         if ((rc = set_max_smem((const void*)k_attn, smem))) return rc;
@@ -1284,7 +1316,8 @@ int q3_dev_bench_gemv(size_t n, size_t d, size_t group_size, int wg_per_cu, int 
         const long cap = (long)prop.multiProcessorCount * (wg_per_cu > 0 ? wg_per_cu : 4);
         gs.grid = (unsigned)(grid > cap ? cap : grid);
     }
-    GemvFn fn = pick<PRO_PREQ, EPI_STORE>((int)group_size, gs.RU, gs.JU);
+    if (ru > 0 || ju > 0) gs.FIN = 0;
+    GemvFn fn = pick<PRO_PREQ, EPI_STORE>((int)group_size, gs.RU, gs.JU, gs.FIN);
     if (!fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel for tile %dx%d", gs.RU, gs.JU);
     const size_t smem = gemv_smem_bytes((int)n, (int)group_size, gs.RU, false);
     if ((rc = set_max_smem((const void*)fn, smem))) return rc;

@@ -233,10 +233,12 @@ struct GemvArgs {
 //   [.., +4*n)                xf   f32    staged activation (PRO_NORM only)
 //   [.., +4*kWaves*vr*NG)     term f32    per-wave group terms
 //   [.., +128*4)              red  f32    block reduction scratch + approximate block totals
-// Exact speculative sum geometry: blocks of kSpecBlen terms, one lane per block, up to 64 blocks (n <= 4096).
-constexpr int kSpecBlen = 64;
-constexpr int kSpecPad = 4;       // floats of padding per block: lane j's b128 reads hit distinct banks (17j mod 64)
-__host__ __device__ inline bool spec_ok(int n) { return n >= 512 && n <= 64 * kSpecBlen && (n % kSpecBlen) == 0; }
+// Exact speculative sum geometry: the n terms are cut into 64 blocks of n/64 terms, one lane per block (n a multiple of
+// 256 in [512, 16384] -> block length a multiple of 4; other n: blocks of 64 terms, up to 64 of them; else a plain chain).
+// Short blocks matter: the fold of a block is a dependent chain of 9-cycle adds, 16 of them for dim 1024.
+constexpr int kSpecPad = 4;       // floats of padding per block: lane j's b128 reads hit distinct banks ((blen+4)j mod 64)
+__host__ __device__ inline bool spec_ok(int n) { return n >= 512 && n <= 16384 && ((n % 256) == 0 || ((n % 64) == 0 && n <= 4096)); }
+__host__ __device__ inline int spec_blen(int n) { return (n % 256) == 0 ? n / 64 : 64; }
 __host__ __device__ inline int term_floats(int n) { return n + 64 * kSpecPad; }
 
 struct GemvSmem {
@@ -344,67 +346,112 @@ __device__ __forceinline__ float seq_chain(float s, const v4f* p, int nq) {
 // LDS float index of term i in the (possibly padded) term array
 __device__ __forceinline__ int term_index(int i, int n) {
     if (!spec_ok(n)) return i;
-    return (i / kSpecBlen) * (kSpecBlen + kSpecPad) + (i % kSpecBlen);
+    const int bl = spec_blen(n);
+    return (i / bl) * (bl + kSpecPad) + (i % bl);
 }
 
-// Exact sequential sum of nblk (<= 64) consecutive blocks of blen terms (blen % 4 == 0); block j starts at
-// t + j*stride (16-byte aligned).  Every lane returns the sum.  approx_tot: optional nblk approximate block totals.
-__device__ __forceinline__ float seq_sum_blocks(const float* t, int nblk, int blen, int stride, const float* approx_tot) {
-    const int nq = blen >> 2;
+// Wave-wide inclusive scan and shift in pure DPP (no LDS crossbar): Hillis-Steele inside the 16-lane rows, then
+// row_bcast:15 (rows 1,3 += last lane of the row below) and row_bcast:31 (rows 2,3 += lane 31).  Used only for GUESSES
+// and corrections whose exactness is verified afterwards, so the association order is free.
+__device__ __forceinline__ float wave_scan_incl(float v) {
+    v += dpp_f<0x111>(v);
+    v += dpp_f<0x112>(v);
+    v += dpp_f<0x114>(v);
+    v += dpp_f<0x118>(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));
+    return v;
+}
+// lane j gets lane j-1's value (wave_shr:1); lane 0 gets +0.0
+__device__ __forceinline__ float wave_prev_lane(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+
+// The guess -> correct -> verify loop shared by every exact sum: lane j < nblk owns block j (blocks in sequence order),
+// `tot` is any approximation of its block total and fold(s) returns the block's exact left fold started from running
+// sum s.  Every lane returns the exact sequential sum over all blocks, started from -0.0.
+template <class Fold>
+__device__ __forceinline__ float spec_sum_lanes(float tot, int nblk, Fold fold) {
     const int j = threadIdx.x & 63;
     const bool live = j < nblk;
-    const v4f* blk = (const v4f*)(t + (size_t)(live ? j : 0) * stride);
-    // inclusive scan over the wave: DPP row_shr within the 16-lane rows, then the row totals of the rows below.
-    // Only used for guesses and corrections, whose exactness is verified afterwards.
-    auto wave_scan = [&](float v) {
-        v += dpp_f<0x111>(v);
-        v += dpp_f<0x112>(v);
-        v += dpp_f<0x114>(v);
-        v += dpp_f<0x118>(v);
-        const float r0 = __shfl(v, 15), r1 = __shfl(v, 31), r2 = __shfl(v, 47);
-        const int row = j >> 4;
-        if (row == 1) v += r0;
-        else if (row == 2) v += r0 + r1;
-        else if (row == 3) v += (r0 + r1) + r2;
-        return v;
-    };
-    auto prev_lane = [&](float v) { return __shfl_up(v, 1); };   // row_shr:1 does not cross DPP rows
-    // approximate block totals: only a guess, any summation order will do
-    float tot = 0.0f;
-    if (approx_tot != nullptr) {
-        if (live) tot = approx_tot[j];
-    } else if (live) {
-        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-        for (int q = 0; q < nq; ++q) {
-            const v4f v = blk[q];
-            p0 += v.x; p1 += v.y; p2 += v.z; p3 += v.w;
-        }
-        tot = (p0 + p1) + (p2 + p3);
-    }
+    if (!live) tot = 0.0f;
     // guesses g_j = running sum before block j: exclusive prefix of the approximate totals
-    float g = prev_lane(wave_scan(tot));
+    float g = wave_prev_lane(wave_scan_incl(tot));
     if (j == 0) g = -0.0f;
-    float out = seq_chain(g, blk, nq);
+    float out = fold(g);
     for (int round = 0; round < 65; ++round) {
         // corrected inputs under the translation assumption.  With e_j = out_{j-1} - g_j (the mismatch at link j)
         // the recurrence s_j = out_{j-1} + (s_{j-1} - g_{j-1}) unrolls to s_j = g_j + sum_{i<=j} e_i: another scan.
         // (Float adds of these few-ulp corrections are normally exact; when they are not, or a tie / binade
         // crossing breaks the translation, the bitwise verification below fails and the loop simply repeats:
         // block 0's input is exact by construction and round r fixes block r.)
-        float e = prev_lane(out) - g;
+        float e = wave_prev_lane(out) - g;
         if (j == 0 || !live) e = 0.0f;
-        e = wave_scan(e);
+        e = wave_scan_incl(e);
         float sc = g + e;
         if (j == 0) sc = -0.0f;
-        const float out2 = seq_chain(sc, blk, nq);
+        const float out2 = fold(sc);
         // verify every link bitwise: input of block j must equal the output of block j-1
-        const float prev = prev_lane(out2);
+        const float prev = wave_prev_lane(out2);
         const bool ok = (j == 0) || !live || (__float_as_uint(prev) == __float_as_uint(sc));
         g = sc;
         out = out2;
         if (__all(ok)) break;
     }
-    return __shfl(out, nblk - 1);   // the last block's output
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(out), nblk - 1));   // the last block's output
+}
+
+// Exact sequential sum of nblk (<= 64) consecutive blocks of blen terms (blen % 4 == 0); block j starts at
+// t + j*stride (16-byte aligned).  Every lane returns the sum.  approx_tot: optional nblk approximate block totals.
+// Blocks of up to kSpecRegQ float4 are pulled into registers once; the folds then run out of VGPRs.
+constexpr int kSpecRegQ = 8;
+template <int NQ>
+__device__ __forceinline__ float chain_regs(float s, const v4f (&r)[kSpecRegQ]) {
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) s = chain4(s, r[k]);
+    return s;
+}
+__device__ __forceinline__ float seq_sum_blocks(const float* t, int nblk, int blen, int stride, const float* approx_tot) {
+    const int nq = blen >> 2;
+    const int j = threadIdx.x & 63;
+    const bool live = j < nblk;
+    const v4f* blk = (const v4f*)(t + (size_t)(live ? j : 0) * stride);
+    const bool in_regs = nq <= kSpecRegQ;        // wave-uniform
+    v4f r[kSpecRegQ];
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < kSpecRegQ; ++k) r[k] = (k < nq) ? blk[k] : v4f{0.f, 0.f, 0.f, 0.f};
+    }
+    // one fold of this lane's block from running sum s: exactly nq float4 (the zero padding of r is never added: -0.0 + 0.0
+    // would flip the sign of an all-zero prefix)
+    auto fold = [&](float s) {
+        if (!in_regs) return seq_chain(s, blk, nq);
+        if (nq == 4) return chain_regs<4>(s, r);
+        if (nq == 8) return chain_regs<8>(s, r);
+        if (nq == 2) return chain_regs<2>(s, r);
+        float acc = s;
+#pragma unroll
+        for (int k = 0; k < kSpecRegQ; ++k) if (k < nq) acc = chain4(acc, r[k]);
+        return acc;
+    };
+    // approximate block totals: only a guess, any summation order will do
+    float tot = 0.0f;
+    if (approx_tot != nullptr) {
+        if (live) tot = approx_tot[j];
+    } else if (live) {
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+        if (in_regs) {
+#pragma unroll
+            for (int k = 0; k < kSpecRegQ; ++k) { p0 += r[k].x; p1 += r[k].y; p2 += r[k].z; p3 += r[k].w; }
+        } else {
+            for (int q = 0; q < nq; ++q) {
+                const v4f v = blk[q];
+                p0 += v.x; p1 += v.y; p2 += v.z; p3 += v.w;
+            }
+        }
+        tot = (p0 + p1) + (p2 + p3);
+    }
+    return spec_sum_lanes(tot, nblk, fold);
 }
 
 // every lane returns the exact sequential sum of the n terms stored (term_index layout) at t
@@ -415,7 +462,8 @@ __device__ __forceinline__ float seq_sum_terms(const float* t, int n, const floa
         for (int i = 0; i < n; ++i) s = s + t[i];
         return s;
     }
-    return seq_sum_blocks(t, n / kSpecBlen, kSpecBlen, kSpecBlen + kSpecPad, approx_tot);
+    const int bl = spec_blen(n);
+    return seq_sum_blocks(t, n / bl, bl, bl + kSpecPad, approx_tot);
 }
 
 // quantize 4 consecutive values held by this thread; its quantization group spans `glanes` = G/4
@@ -569,8 +617,9 @@ __device__ __forceinline__ void gemv_prologue_finish(const GemvArgs& a, const Ge
     }
     // PRO_NORM / PRO_EMBED_NORM: x -> RMSNorm (layers.rs:109-119) -> quantize (tensor.rs:91-119)
     float part = 0.0f;
-    constexpr int lanes_per_block = kSpecBlen >> 2;         // 16 float4 slots (threads) per speculative block
-    const bool have_approx = spec_ok(n) && nk <= kProSlots && (nv % kWG) == 0;
+    const int lanes_per_block = spec_blen(n) >> 2;          // float4 slots (consecutive threads) per speculative block
+    const bool have_approx = spec_ok(n) && nk <= kProSlots && (nv % kWG) == 0 && lanes_per_block <= 16 &&
+                             (lanes_per_block & (lanes_per_block - 1)) == 0;
 #pragma unroll
     for (int k = 0; k < kProSlots; ++k) {
         const int v = k * kWG + tid;
@@ -696,7 +745,10 @@ __device__ __forceinline__ float ordered_row_sum(const float* t, int ng) {
     return acc;
 }
 
-template <int PRO, int EPI, int LPG_T, int RU, int JU>
+// FIN = 1 (latency-bound launches, G = 64, rows a whole number of tiles): the group terms never touch LDS.  After the DPP
+// all-reduce every lane of a group holds the group's term; the row's sum is folded in ascending group order by a chain
+// of v_add with the terms pulled into SGPRs by v_readlane -- the accumulator is wave-uniform and carries across tiles.
+template <int PRO, int EPI, int LPG_T, int RU, int JU, int FIN = 0>
 __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     stamp(a, 0);
@@ -793,7 +845,36 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
             }
         }
     };
+    float racc[RU];                                  // FIN: running row sums (wave-uniform)
     auto compute_tile = [&](const Tile<RU, JU>& T, const RowSrc& rs, int jt) {
+        if constexpr (FIN != 0) {
+            static_assert(FIN == 0 || LPG_T == 4, "the register fold is written for group 64");
+            if (jt == 0) {
+#pragma unroll
+                for (int r = 0; r < RU; ++r) racc[r] = -0.0f;          // Iterator::sum identity (tensor.rs:53-60)
+            }
+#pragma unroll
+            for (int j = 0; j < JU; ++j) {
+                const int c = lane + 64 * (jt * JU + j);
+                const v4i xv = ((const v4i*)sm.xq)[c];
+                const float xsc = sm.xs[c >> 2];
+#pragma unroll
+                for (int r = 0; r < RU; ++r) {
+                    int d = __builtin_amdgcn_sdot4(T.w[r][j].x, xv.x, 0, false);
+                    d = __builtin_amdgcn_sdot4(T.w[r][j].y, xv.y, d, false);
+                    d = __builtin_amdgcn_sdot4(T.w[r][j].z, xv.z, d, false);
+                    d = __builtin_amdgcn_sdot4(T.w[r][j].w, xv.w, d, false);
+                    d = group_sum_i32_t<4>(d);
+                    float t = (float)d * T.sc[r][j];   // tensor.rs:59  ((dot as f32) * ws) * xs -- identical in the 4 lanes of a group
+                    t = t * xsc;
+                    const int ti = __float_as_int(t);
+#pragma unroll
+                    for (int g = 0; g < 16; ++g)
+                        racc[r] = racc[r] + __int_as_float(__builtin_amdgcn_readlane(ti, 4 * g));
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < JU; ++j) {
             const int c = lane + 64 * (jt * JU + j);
@@ -819,15 +900,28 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
     };
     unsigned long long best = 0ull;  // EPI_LOGITS running argmax key
     auto finish = [&](const RowSrc& rs) {
-        wave_lds_sync();
+        if constexpr (FIN == 0) wave_lds_sync();
         if (lane < rs.cnt) {
-            const float acc = Q3_DEV_ABLATE(a, 4) ? term[lane * ng] : ordered_row_sum(term + lane * ng, ng);
+            float acc, up = 0.0f;
+            if constexpr (FIN != 0) {
+                acc = racc[0];
+#pragma unroll
+                for (int r = 1; r < HU; ++r) acc = (lane == r) ? racc[r] : acc;
+                if constexpr (EPI == EPI_SWIGLU) {
+                    up = racc[HU];
+#pragma unroll
+                    for (int r = 1; r < HU; ++r) up = (lane == r) ? racc[HU + r] : up;
+                }
+            } else {
+                acc = Q3_DEV_ABLATE(a, 4) ? term[lane * ng] : ordered_row_sum(term + lane * ng, ng);
+            }
             if (EPI == EPI_STORE || EPI == EPI_QKV) {
                 rs.out[lane] = acc;
             } else if (EPI == EPI_RESID) {
                 rs.out[lane] = rs.resid + acc;          // ResidualConnection::forward, layers.rs:249-259
             } else if (EPI == EPI_SWIGLU) {
-                const float u = ordered_row_sum(term + (lane + HU) * ng, ng);
+                float u = up;
+                if constexpr (FIN == 0) u = ordered_row_sum(term + (lane + HU) * ng, ng);
                 const float den = 1.0f + q3_expf(-acc);   // layers.rs:472-475
                 const float sw = acc * (1.0f / den);
                 rs.out[lane] = sw * u;
@@ -838,7 +932,7 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
                 best = key > best ? key : best;
             }
         }
-        wave_lds_sync();
+        if constexpr (FIN == 0) wave_lds_sync();
     };
 
     // ---- flat tile sequence of this wave: (batch b, tile jt), b = gw, gw+nwaves, ...
@@ -1288,6 +1382,201 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a) {
             out[i] = r;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Short-context attention (pos < 256, head_dim 64 or 128): one 4-wave workgroup per query head, NO K/V staging in LDS.
+//   * wave w owns timesteps [64w, 64w+64): lane t keeps its K row in registers (HD/4 dwordx4 loads issued at entry, in
+//     flight under the norm) and walks the reference's sequential dot (layers.rs:395-400) against q broadcast from LDS;
+//     the current position's key comes from this kernel (LDS), selected per lane;
+//   * waves 0/1 meanwhile do the QK-RMSNorm + RoPE of q / k (layers.rs:346-372): the HD-term sum of squares is the exact
+//     speculative scan over HD/8 lanes x 8 terms, entirely in registers;
+//   * after ONE barrier on the scores every wave reads them back 4 per lane and does the softmax redundantly (max,
+//     glibc expf, exact sequential sum = speculative scan over 64 lanes x 4 terms) -- no further barrier;
+//   * the last HD/64 waves own the output elements: V[t][e] arrives by coalesced 4-byte loads (32 timesteps per register
+//     set, double buffered, first two sets requested at entry), the probability of timestep t is pulled into an SGPR by
+//     v_readlane and the chain o += p_t * v_t runs in t order (layers.rs:406-417).
+// Every sum is in the reference's order => bit-identical to k_attn / the CPU path.  Used in both modes (the default mode's
+// tolerance is trivially met).
+// ------------------------------------------------------------------------------------------------
+constexpr int kShortMaxT = 256;
+#ifdef Q3_DEV
+#define ATTS_STAMP(i, thr) do { if (a.stamps != nullptr && blockIdx.x == 3 && (int)threadIdx.x == (thr)) a.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ATTS_STAMP(i, thr) do { } while (0)
+#endif
+template <int HD>
+__global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
+    static_assert(HD == 64 || HD == 128, "head dims instantiated");
+    constexpr int NQ4 = HD / 4;          // float4 per K row
+    constexpr int HALF = HD / 2;         // rotate-half pairing (i, i + HD/2)
+    constexpr int NVW = HD / 64;         // waves that own output elements (the last NVW of the workgroup)
+    constexpr int NB = HD / 8;           // 8-term blocks of the sum of squares, one lane each
+    __shared__ __attribute__((aligned(16))) float q_s[HD];
+    __shared__ __attribute__((aligned(16))) float k_s[HD];
+    __shared__ __attribute__((aligned(16))) float att[kShortMaxT];
+    ATTS_STAMP(0, 0);
+
+    const int h = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kv_mul = a.n_heads / a.n_kv_heads;
+    const int kvh = h / kv_mul;
+    const size_t kvd = (size_t)a.n_kv_heads * HD;
+    const int pos = a.pos_override >= 0 ? a.pos_override : a.st->pos;
+    const int np = pos + 1;
+    const float* kbase = a.key_cache + (size_t)kvh * HD;
+    const float* vbase = a.value_cache + (size_t)kvh * HD;
+
+    // ---- everything this workgroup will read is requested up front
+    const bool is_q = wave == 0, is_k = wave == 1;
+    float r_lo = 0.f, r_hi = 0.f, w_lo = 0.f, w_hi = 0.f, rc = 0.f, rs = 0.f;
+    v4f rb0 = {0.f, 0.f, 0.f, 0.f}, rb1 = {0.f, 0.f, 0.f, 0.f};
+    if (wave < 2) {
+        const float* rawp = is_q ? a.q + (size_t)h * HD : a.k_raw + (size_t)kvh * HD;
+        const int i = min(lane, HALF - 1);
+        r_lo = rawp[i];
+        r_hi = rawp[i + HALF];
+        const int jb = min(lane, NB - 1);
+        rb0 = ((const v4f*)rawp)[2 * jb];
+        rb1 = ((const v4f*)rawp)[2 * jb + 1];
+        const float* nw = is_q ? a.q_norm_w : a.k_norm_w;
+        w_lo = nw[i];
+        w_hi = nw[i + HALF];
+        const float* cs = a.rope + (size_t)pos * HD;      // HD/2 (cos,sin) pairs of this position
+        rc = cs[2 * i];
+        rs = cs[2 * i + 1];
+    }
+    const int t = 64 * wave + lane;
+    const bool wave_has_t = 64 * wave < np;               // wave-uniform
+    v4f kr[NQ4];
+    if (wave_has_t) {
+        // rows past the context re-read row pos (one cache line for all of them); row pos itself still holds whatever
+        // an earlier pass left there -- both are replaced / masked below
+        const v4f* kp = (const v4f*)(kbase + (size_t)min(t, pos) * kvd);
+#pragma unroll
+        for (int i = 0; i < NQ4; ++i) kr[i] = kp[i];
+    }
+    const bool is_v = wave >= 4 - NVW;                    // wave-uniform
+    const int e = 64 * (wave - (4 - NVW)) + lane;         // output element of this lane (V waves)
+    float va[32], vb[32];
+    auto v_issue = [&](float (&R)[32], int c) {
+        const float* vp = vbase + e;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) R[u] = vp[(size_t)min(32 * c + u, pos) * kvd];
+    };
+    if (is_v) {
+        v_issue(va, 0);
+        if (np > 32) v_issue(vb, 1);
+    }
+    ATTS_STAMP(1, 0);
+
+    // ---- waves 0/1: RMSNorm (layers.rs:109-119) + RoPE (layers.rs:173-185) of q / k
+    if (wave < 2) {
+        v4f s0, s1;
+        s0.x = rb0.x * rb0.x; s0.y = rb0.y * rb0.y; s0.z = rb0.z * rb0.z; s0.w = rb0.w * rb0.w;
+        s1.x = rb1.x * rb1.x; s1.y = rb1.y * rb1.y; s1.z = rb1.z * rb1.z; s1.w = rb1.w * rb1.w;
+        const float tot = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w));
+        const float ss = spec_sum_lanes(tot, NB, [&](float s) { s = chain4(s, s0); return chain4(s, s1); });
+        const float f = 1.0f / sqrtf(ss / (float)HD + kEps);
+        if (lane < HALF) {
+            const float xv = w_lo * (f * r_lo);
+            const float yv = w_hi * (f * r_hi);
+            const float a0 = xv * rc, b0 = yv * rs;
+            const float a1 = xv * rs, b1 = yv * rc;
+            const float lo = a0 - b0, hi = a1 + b1;          // layers.rs:181-182
+            float* dst = is_q ? q_s : k_s;
+            dst[lane] = lo;
+            dst[lane + HALF] = hi;
+            if (is_k && (h % kv_mul) == 0) {                  // K is normalised + rotated in place in the cache
+                float* krow = a.key_cache + (size_t)pos * kvd + (size_t)kvh * HD;
+                krow[lane] = lo;
+                krow[lane + HALF] = hi;
+            }
+            if (is_q && a.write_q) {
+                a.q[(size_t)h * HD + lane] = lo;
+                a.q[(size_t)h * HD + lane + HALF] = hi;
+            }
+        }
+    }
+    ATTS_STAMP(2, 0);
+    __syncthreads();
+    ATTS_STAMP(3, 0);
+
+    // ---- scores: att[t] = (q . K[t]) * scale, the dot walked in index order       layers.rs:391-401
+    const float scale = 1.0f / sqrtf((float)HD);
+    float sc = -__builtin_inff();
+    if (wave_has_t) {
+        const bool is_pos = t == pos;
+        float dot = -0.0f;
+#pragma unroll
+        for (int i = 0; i < NQ4; ++i) {
+            const v4f qv = ((const v4f*)q_s)[i];
+            const v4f kn = ((const v4f*)k_s)[i];
+            v4f kk = kr[i];
+            kk.x = is_pos ? kn.x : kk.x;
+            kk.y = is_pos ? kn.y : kk.y;
+            kk.z = is_pos ? kn.z : kk.z;
+            kk.w = is_pos ? kn.w : kk.w;
+            float p = qv.x * kk.x; dot = dot + p;
+            p = qv.y * kk.y; dot = dot + p;
+            p = qv.z * kk.z; dot = dot + p;
+            p = qv.w * kk.w; dot = dot + p;
+        }
+        if (t < np) sc = dot * scale;
+    }
+    att[t] = sc;                                          // all 256 slots are written: -inf beyond the context
+    __syncthreads();
+    ATTS_STAMP(4, 0);
+
+    // ---- softmax (layers.rs:495-506), redundantly in every wave: lane l holds timesteps 4l .. 4l+3
+    const v4f s4 = ((const v4f*)att)[lane];
+    float m = fmaxf(fmaxf(s4.x, s4.y), fmaxf(s4.z, s4.w));
+    m = group_max_f32(m, 64);
+    const int t4 = 4 * lane;
+    v4f e4;
+    e4.x = q3_expf(t4 + 0 < np ? s4.x - m : 0.0f);
+    e4.y = q3_expf(t4 + 1 < np ? s4.y - m : 0.0f);
+    e4.z = q3_expf(t4 + 2 < np ? s4.z - m : 0.0f);
+    e4.w = q3_expf(t4 + 3 < np ? s4.w - m : 0.0f);
+    e4.x = t4 + 0 < np ? e4.x : 0.0f;                    // +0.0 past the context: leaves every partial sum unchanged
+    e4.y = t4 + 1 < np ? e4.y : 0.0f;
+    e4.z = t4 + 2 < np ? e4.z : 0.0f;
+    e4.w = t4 + 3 < np ? e4.w : 0.0f;
+    const float etot = (e4.x + e4.y) + (e4.z + e4.w);
+    const float sum = spec_sum_lanes(etot, (np + 3) >> 2, [&](float s) { return chain4(s, e4); });
+    const float inv = 1.0f / sum;
+    int p4[4];
+    p4[0] = __float_as_int(e4.x * inv);
+    p4[1] = __float_as_int(e4.y * inv);
+    p4[2] = __float_as_int(e4.z * inv);
+    p4[3] = __float_as_int(e4.w * inv);
+    ATTS_STAMP(5, kWG - 64);
+
+    // ---- xb = sum_t att[t] * V[t], one chain per output element in t order          layers.rs:406-417
+    if (is_v) {
+        float o = 0.0f;
+        auto fold_chunk = [&](const float (&R)[32], int c) {
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                // probability of timestep 32c+u sits in lane 8c + u/4, component u%4 (0 past the context)
+                const float pv = __int_as_float(__builtin_amdgcn_readlane(p4[u & 3], 8 * c + (u >> 2)));
+                const float vv = (32 * c + u < np) ? R[u] : 0.0f;
+                const float pr = pv * vv;
+                o = o + pr;
+            }
+        };
+        for (int c = 0; 32 * c < np; c += 2) {
+            fold_chunk(va, c);
+            if (32 * (c + 2) < np) v_issue(va, c + 2);
+            if (32 * (c + 1) < np) {
+                fold_chunk(vb, c + 1);
+                if (32 * (c + 3) < np) v_issue(vb, c + 3);
+            }
+        }
+        a.xb[(size_t)h * HD + e] = o;
+    }
+    ATTS_STAMP(6, kWG - 64);
 }
 
 // ------------------------------------------------------------------------------------------------

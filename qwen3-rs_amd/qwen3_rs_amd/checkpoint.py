@@ -107,6 +107,7 @@ SHAPES: Dict[str, ModelShape] = {
     "small-longctx": ModelShape(256, 512, 2, 4, 2, 512, 2048, 64, True, 64),
     # the real 4B / 8B layer dimensions with 2 layers and a reduced vocabulary: parity-test cases for
     # BASELINE configs 3-5 that the CPU oracle finishes in seconds (n = 2560, 9728, 4096, 12288; kv_mul 4)
+    "qwen3-0.6b-dims-l2": ModelShape(1024, 3072, 2, 16, 8, 4096, 1024, 128, True, 64),
     "qwen3-4b-dims-l2": ModelShape(2560, 9728, 2, 32, 8, 16384, 4096, 128, True, 64),
     "qwen3-8b-dims-l2": ModelShape(4096, 12288, 2, 32, 8, 16384, 4096, 128, False, 64),
 }

@@ -253,6 +253,42 @@ def test_big_layer_dims_vs_oracle(q3, oracle, name):
         assert t.generate_greedy(tok, 9, 3) == want
 
 
+def test_0p6b_dims_every_position_to_the_split_vs_oracle(q3, oracle):
+    """The headline shape's layer dimensions (dim 1024, hidden 3072, 16 heads over 8 kv heads) with 2 layers: a 270-token
+    sequence forwarded from position 0 crosses every 64-timestep wave boundary of the short-context attention kernel, its
+    32-timestep V register sets and the hand-over to the split kernels at pos 256.  Tokens, the final logits and both
+    KV caches are compared with the oracle bit for bit (the latency-bound GEMV variants with the register fold of the
+    group terms are the ones this shape selects)."""
+    ck = q3.checkpoint
+    name = "qwen3-0.6b-dims-l2"
+    sh = ck.SHAPES[name]
+    path = os.path.join(os.environ.get("Q3_CKPT_DIR", "/tmp"), f"q3_{name}.bin")
+    ck.ensure_synthetic_checkpoint(path, sh, seed=77)
+    n = 270
+    om = oracle.OracleModel(path, 320)
+    toks = [int(v) for v in np.random.default_rng(3).integers(0, sh.vocab_size, size=n)]
+    for p in range(n):                                      # chat-mode pattern: every token forwarded (generation.rs:116-123)
+        lg = om.forward(toks[p], p)
+    nxt = oracle.sample_argmax(lg)
+    want, tk = [], nxt
+    for p in range(n, n + 6):
+        tk = oracle.sample_argmax(om.forward(tk, p))
+        want.append(tk)
+    with q3.TransformerBuilder(path).with_ctx_length(320).build() as t:
+        assert t.prefill(toks, 0) == nxt
+        assert t.generate_greedy(nxt, n, 6) == want
+        n = n + 6
+        kvd = sh.n_kv_heads * sh.head_dim
+        ok, ov = om.kv_cache()
+        for layer in range(sh.n_layers):
+            assert_biteq(t.read_state("key", layer * 320 * kvd, n * kvd), ok.reshape(sh.n_layers, -1)[layer][:n * kvd], "key cache")
+            assert_biteq(t.read_state("value", layer * 320 * kvd, n * kvd), ov.reshape(sh.n_layers, -1)[layer][:n * kvd], "value cache")
+        t.reset_kv()
+        om.reset()
+        for p in (0, 1, 2):                                 # the forward() surface on a fresh cache
+            assert_biteq(np.array(t.forward(5, p), copy=True), om.forward(5, p), f"forward(5,{p})")
+
+
 def test_long_context_split_attention_vs_oracle(q3, oracle, tmp_ckpt_dir):
     """pos >= 256 switches the engine to the long-context launch plan (scores over heads x T-chunks, softmax + V over
     heads x element slices).  Logits stay bit-identical across the switch, at chunk boundaries and deep into the

@@ -1,0 +1,16 @@
+#!/bin/bash
+# iteration pass: GPU tests, 128-token bench line, in-kernel timelines (dev build)
+out=gpurun_out/${1:-iter}; mkdir -p $out
+timeout 900 python -m pytest tests -m gpu -x -q > $out/pytest.log 2>&1; echo "pytest rc=$?" >> $out/pytest.log
+tail -5 $out/pytest.log
+timeout 600 python bench.py --no-other-configs > $out/bench128.json 2> $out/bench128.err; echo "bench128 rc=$?"
+python3 - <<PY
+import json
+try:
+    d=json.load(open("$out/bench128.json"))
+    print("tok/s", d["value"], "parity", d.get("parity"), "fs", d.get("forward_surface",{}).get("value"), "frac", d["roofline"]["frac"])
+    print([(k["kernel"],k["avg_us"]) for k in d["roofline"]["per_kernel"]])
+except Exception as e: print("bench parse failed", e)
+PY
+Q3_STAMPS=1 Q3_STRICT=1 Q3_HIP_LIB=qwen3-rs_amd/libqwen3_hip_dev.so Q3_NTOK=32 timeout 300 python tools/gen_loop.py > $out/stamps.log 2>&1
+tail -9 $out/stamps.log
