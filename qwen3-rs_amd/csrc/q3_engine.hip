@@ -135,8 +135,8 @@ struct Launch {
 };
 
 // tile shapes instantiated: group 64 (every listed model) gets the full set, other group sizes a
-// single-row-run fallback (RU = 1, or 2 for SwiGLU).  FIN = 1 (register fold of the group terms, latency-bound launches)
-// exists for group 64 with RU <= 2.
+// single-row-run fallback (RU = 1, or 2 for SwiGLU).  FIN = 1 (DPP-chain fold of the group terms, latency-bound
+// launches) exists for group 64.
 template <int PRO, int EPI, int LPG_T, int RU, int FIN = 0>
 GemvFn pick_ju(int JU) {
     if (JU == 1) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 1, FIN>;
@@ -151,6 +151,8 @@ GemvFn pick(int G, int RU, int JU, int FIN = 0) {
     if (G == 64) {
         if constexpr (EPI != EPI_LOGITS) {
             if (FIN) {
+                if (RU == 8) return pick_ju<PRO, EPI, 4, 8, 1>(JU);
+                if (RU == 4) return pick_ju<PRO, EPI, 4, 4, 1>(JU);
                 if (RU == 2) return pick_ju<PRO, EPI, 4, 2, 1>(JU);
                 if constexpr (!sw) { if (RU == 1) return pick_ju<PRO, EPI, 4, 1, 1>(JU); }
                 return nullptr;
@@ -280,19 +282,8 @@ GemvShape plan_gemv(int units, int n, int G, bool swiglu, int row_align, int n_c
     if (force_ju >= 1 && force_ju <= 4) g.JU = force_ju;
     const int ru_max = 8 / g.JU, ru_min = swiglu ? 2 : 1;
     const int waves = n_cu * wg_per_cu * kWaves;
-    // latency-bound launches whose rows are a whole number of tiles: register fold of the group terms (k_gemv FIN = 1),
-    // one or two rows per wave batch
-    if (allow_fin && env_int("Q3_GEMV_FIN", 1) && G == 64 && nchunks % (64 * g.JU) == 0 && launch_bytes < (16u << 20)) {
-        g.FIN = 1;
-        const bool two = swiglu || ((units + waves - 1) / waves >= 2 && (row_align <= 1 || row_align % 2 == 0) && g.JU <= 4);
-        g.RU = two ? 2 : 1;
-        const int hu = swiglu ? 1 : g.RU;
-        const long nb = (units + hu - 1) / hu;
-        long grid = (nb + kWaves - 1) / kWaves;
-        if (grid > (long)n_cu * wg_per_cu) grid = (long)n_cu * wg_per_cu;
-        g.grid = (unsigned)(grid < 1 ? 1 : grid);
-        return g;
-    }
+    // latency-bound launches whose rows are a whole number of tiles fold the group terms in registers (k_gemv FIN = 1)
+    if (allow_fin && env_int("Q3_GEMV_FIN", 1) && G == 64 && nchunks % (64 * g.JU) == 0 && launch_bytes < (16u << 20)) g.FIN = 1;
     int best_ru = ru_min;
     long best_cost = -1;
     for (int ru = ru_max; ru >= ru_min; ru >>= 1) {

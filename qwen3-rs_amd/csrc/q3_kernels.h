@@ -367,38 +367,91 @@ __device__ __forceinline__ float wave_prev_lane(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
 }
 
-// The guess -> correct -> verify loop shared by every exact sum: lane j < nblk owns block j (blocks in sequence order),
-// `tot` is any approximation of its block total and fold(s) returns the block's exact left fold started from running
-// sum s.  Every lane returns the exact sequential sum over all blocks, started from -0.0.
+// The guess -> correct -> verify scheme shared by every exact sum: lane j < nblk owns block j (blocks in sequence
+// order), `tot` is any approximation of its block total and fold(s) returns the block's exact left fold started from
+// running sum s.  Every lane returns the exact sequential sum over all blocks, started from -0.0.
+//
+// Round 1 folds every block from a guessed running sum (exclusive scan of the approximate totals); the mismatches at the
+// links, prefix-summed, give corrected inputs sc_j (adding a block to a running sum is a translation as long as the sum
+// stays in one binade).  Where the running sum crosses a power of two inside a block the f32 grid coarsens and the
+// corrected input can still be a float step or two off -- and every later crossing would cost another round.  So round 2
+// folds FIVE candidates per block, sc_j stepped by -2..+2 floats (independent chains: they fill the 9-cycle add
+// latency), and each lane records where its predecessor's five outputs land relative to its own candidates: a map
+// c -> c' in {-2..2, fail}.  Almost every link maps c -> c ("transparent"); the few that do not (crossings, ties) are
+// walked in lane order with scalar code, starting from c = 0 at block 0, whose input -0.0 is exact by construction.
+// Every link on the selected path is a bitwise match of a block output with the next block's input, so the result IS the
+// sequential fold.  If the path leaves the window the plain iteration (round r fixes block r) finishes the job.
+constexpr int kCandK = 2;
 template <class Fold>
 __device__ __forceinline__ float spec_sum_lanes(float tot, int nblk, Fold fold) {
     const int j = threadIdx.x & 63;
     const bool live = j < nblk;
     if (!live) tot = 0.0f;
-    // guesses g_j = running sum before block j: exclusive prefix of the approximate totals
+    // ---- round 1: guesses g_j = running sum before block j = exclusive prefix of the approximate totals
     float g = wave_prev_lane(wave_scan_incl(tot));
     if (j == 0) g = -0.0f;
     float out = fold(g);
+    // corrected inputs: with e_j = out_{j-1} - g_j the recurrence s_j = out_{j-1} + (s_{j-1} - g_{j-1}) unrolls to
+    // s_j = g_j + sum_{i<=j} e_i: another scan
+    float e = wave_prev_lane(out) - g;
+    if (j == 0 || !live) e = 0.0f;
+    e = wave_scan_incl(e);
+    float sc = g + e;
+    if (j == 0) sc = -0.0f;
+    // ---- round 2: five candidate inputs per block
+    float o[2 * kCandK + 1];
+#pragma unroll
+    for (int c = -kCandK; c <= kCandK; ++c) {
+        const float in = (j == 0) ? -0.0f : __int_as_float(__float_as_int(sc) + c);
+        o[c + kCandK] = fold(in);
+    }
+    // link map of lane j: predecessor's output under its candidate c == my candidate c' ?
+    const int scb = __float_as_int(sc);
+    unsigned pk = 0;
+    bool transparent = true;
+#pragma unroll
+    for (int c = -kCandK; c <= kCandK; ++c) {
+        const int d = __float_as_int(wave_prev_lane(o[c + kCandK])) - scb;
+        const bool in_win = d >= -kCandK && d <= kCandK;
+        pk |= (in_win ? (unsigned)(d + kCandK) : 7u) << (3 * (c + kCandK));
+        transparent = transparent && (d == c);
+    }
+    if (j == 0 || !live) transparent = true;
+    unsigned long long walk = __ballot(!transparent);
+    int c = 0;
+    bool lost = false;
+    while (walk != 0ull) {
+        const int l = __builtin_ctzll(walk);
+        walk &= walk - 1ull;
+        const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)pk, l);
+        const unsigned v = (m >> (3 * (c + kCandK))) & 7u;
+        if (v == 7u) { lost = true; break; }
+        c = (int)v - kCandK;
+    }
+    if (!lost) {
+        float res = o[0];
+#pragma unroll
+        for (int k = 1; k <= 2 * kCandK; ++k) res = (c + kCandK == k) ? o[k] : res;
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res), nblk - 1));   // the last block's output
+    }
+    // ---- rare: the plain iteration.  Block 0's input is exact by construction and round r fixes block r.
+    g = sc;
+    out = o[kCandK];
     for (int round = 0; round < 65; ++round) {
-        // corrected inputs under the translation assumption.  With e_j = out_{j-1} - g_j (the mismatch at link j)
-        // the recurrence s_j = out_{j-1} + (s_{j-1} - g_{j-1}) unrolls to s_j = g_j + sum_{i<=j} e_i: another scan.
-        // (Float adds of these few-ulp corrections are normally exact; when they are not, or a tie / binade
-        // crossing breaks the translation, the bitwise verification below fails and the loop simply repeats:
-        // block 0's input is exact by construction and round r fixes block r.)
-        float e = wave_prev_lane(out) - g;
-        if (j == 0 || !live) e = 0.0f;
-        e = wave_scan_incl(e);
-        float sc = g + e;
-        if (j == 0) sc = -0.0f;
-        const float out2 = fold(sc);
+        float e2 = wave_prev_lane(out) - g;
+        if (j == 0 || !live) e2 = 0.0f;
+        e2 = wave_scan_incl(e2);
+        float s2 = g + e2;
+        if (j == 0) s2 = -0.0f;
+        const float out2 = fold(s2);
         // verify every link bitwise: input of block j must equal the output of block j-1
         const float prev = wave_prev_lane(out2);
-        const bool ok = (j == 0) || !live || (__float_as_uint(prev) == __float_as_uint(sc));
-        g = sc;
+        const bool ok = (j == 0) || !live || (__float_as_uint(prev) == __float_as_uint(s2));
+        g = s2;
         out = out2;
         if (__all(ok)) break;
     }
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(out), nblk - 1));   // the last block's output
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(out), nblk - 1));
 }
 
 // Exact sequential sum of nblk (<= 64) consecutive blocks of blen terms (blen % 4 == 0); block j starts at
@@ -747,7 +800,8 @@ __device__ __forceinline__ float ordered_row_sum(const float* t, int ng) {
 
 // FIN = 1 (latency-bound launches, G = 64, rows a whole number of tiles): the group terms never touch LDS.  After the DPP
 // all-reduce every lane of a group holds the group's term; the row's sum is folded in ascending group order by a chain
-// of v_add with the terms pulled into SGPRs by v_readlane -- the accumulator is wave-uniform and carries across tiles.
+// of 16 DPP adds per 1 KiB chunk (the running sum hops from group to group, lane 4g+3 -> 4g+7), all rows of the tile in
+// flight together; the chunk total is read from lane 63 and carries into the next chunk / tile.
 template <int PRO, int EPI, int LPG_T, int RU, int JU, int FIN = 0>
 __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -867,10 +921,15 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
                     d = group_sum_i32_t<4>(d);
                     float t = (float)d * T.sc[r][j];   // tensor.rs:59  ((dot as f32) * ws) * xs -- identical in the 4 lanes of a group
                     t = t * xsc;
-                    const int ti = __float_as_int(t);
+                    // ascending-group fold as a chain of DPP adds: group g's running sum lives in lane 4g+3 and moves to
+                    // lane 4g+7 by row_shr:4 (row_bcast:15 across the 16-lane rows); lane 63 ends with the chunk's sum
+                    float acc = racc[r] + t;
 #pragma unroll
-                    for (int g = 0; g < 16; ++g)
-                        racc[r] = racc[r] + __int_as_float(__builtin_amdgcn_readlane(ti, 4 * g));
+                    for (int g = 1; g < 16; ++g) {
+                        const float prev = (g & 3) ? dpp_f<0x114>(acc) : dpp_f<0x142>(acc);
+                        acc = prev + t;
+                    }
+                    racc[r] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 63));
                 }
             }
             return;
