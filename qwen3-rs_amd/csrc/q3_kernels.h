@@ -367,144 +367,89 @@ __device__ __forceinline__ float wave_prev_lane(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
 }
 
-// The guess -> correct -> verify scheme shared by every exact sum: lane j < nblk owns block j (blocks in sequence
-// order), `tot` is any approximation of its block total and fold(s) returns the block's exact left fold started from
-// running sum s.  Every lane returns the exact sequential sum over all blocks, started from -0.0.
-//
-// Round 1 folds every block from a guessed running sum (exclusive scan of the approximate totals); the mismatches at the
-// links, prefix-summed, give corrected inputs sc_j (adding a block to a running sum is a translation as long as the sum
-// stays in one binade).  Where the running sum crosses a power of two inside a block the f32 grid coarsens and the
-// corrected input can still be a float step or two off -- and every later crossing would cost another round.  So round 2
-// folds FIVE candidates per block, sc_j stepped by -2..+2 floats (independent chains: they fill the 9-cycle add
-// latency), and each lane records where its predecessor's five outputs land relative to its own candidates: a map
-// c -> c' in {-2..2, fail}.  Almost every link maps c -> c ("transparent"); the few that do not (crossings, ties) are
-// walked in lane order with scalar code, starting from c = 0 at block 0, whose input -0.0 is exact by construction.
-// Every link on the selected path is a bitwise match of a block output with the next block's input, so the result IS the
-// sequential fold.  If the path leaves the window the plain iteration (round r fixes block r) finishes the job.
-constexpr int kCandK = 2;
+// The guess -> correct -> verify loop shared by every exact sum: lane j < nblk owns block j (blocks in sequence order),
+// `tot` is any approximation of its block total and fold(s) returns the block's exact left fold started from running
+// sum s.  Every lane returns the exact sequential sum over all blocks, started from -0.0.
+// Measured on MI355X (tools/sum_probe.hip, 1024 squares of N(0,s) data): a round costs ~400 cycles with 16-term blocks
+// (fold 160 + scan 100 + shifts/compare ~140) and 4-8 rounds are needed -- one per power of two the running sum crosses
+// inside the speculated range, because the f32 grid coarsens there and a correction of a few fine ulps is no longer a
+// translation.  (Tried and dropped: a second round with five candidate inputs per block and a scalar walk over the
+// non-transparent links -- exact, deterministic round count, but 1.3-1.6x slower than iterating.)
 template <class Fold>
 __device__ __forceinline__ float spec_sum_lanes(float tot, int nblk, Fold fold) {
     const int j = threadIdx.x & 63;
     const bool live = j < nblk;
     if (!live) tot = 0.0f;
-    // ---- round 1: guesses g_j = running sum before block j = exclusive prefix of the approximate totals
-    float g = wave_prev_lane(wave_scan_incl(tot));
-    if (j == 0) g = -0.0f;
-    float out = fold(g);
-    // corrected inputs: with e_j = out_{j-1} - g_j the recurrence s_j = out_{j-1} + (s_{j-1} - g_{j-1}) unrolls to
-    // s_j = g_j + sum_{i<=j} e_i: another scan
-    float e = wave_prev_lane(out) - g;
-    if (j == 0 || !live) e = 0.0f;
-    e = wave_scan_incl(e);
-    float sc = g + e;
+    // guesses g_j = running sum before block j: exclusive prefix of the approximate totals
+    float sc = wave_prev_lane(wave_scan_incl(tot));
     if (j == 0) sc = -0.0f;
-    // ---- round 2: five candidate inputs per block
-    float o[2 * kCandK + 1];
-#pragma unroll
-    for (int c = -kCandK; c <= kCandK; ++c) {
-        const float in = (j == 0) ? -0.0f : __int_as_float(__float_as_int(sc) + c);
-        o[c + kCandK] = fold(in);
-    }
-    // link map of lane j: predecessor's output under its candidate c == my candidate c' ?
-    const int scb = __float_as_int(sc);
-    unsigned pk = 0;
-    bool transparent = true;
-#pragma unroll
-    for (int c = -kCandK; c <= kCandK; ++c) {
-        const int d = __float_as_int(wave_prev_lane(o[c + kCandK])) - scb;
-        const bool in_win = d >= -kCandK && d <= kCandK;
-        pk |= (in_win ? (unsigned)(d + kCandK) : 7u) << (3 * (c + kCandK));
-        transparent = transparent && (d == c);
-    }
-    if (j == 0 || !live) transparent = true;
-    unsigned long long walk = __ballot(!transparent);
-    int c = 0;
-    bool lost = false;
-    while (walk != 0ull) {
-        const int l = __builtin_ctzll(walk);
-        walk &= walk - 1ull;
-        const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)pk, l);
-        const unsigned v = (m >> (3 * (c + kCandK))) & 7u;
-        if (v == 7u) { lost = true; break; }
-        c = (int)v - kCandK;
-    }
-    if (!lost) {
-        float res = o[0];
-#pragma unroll
-        for (int k = 1; k <= 2 * kCandK; ++k) res = (c + kCandK == k) ? o[k] : res;
-        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res), nblk - 1));   // the last block's output
-    }
-    // ---- rare: the plain iteration.  Block 0's input is exact by construction and round r fixes block r.
-    g = sc;
-    out = o[kCandK];
-    for (int round = 0; round < 65; ++round) {
-        float e2 = wave_prev_lane(out) - g;
-        if (j == 0 || !live) e2 = 0.0f;
-        e2 = wave_scan_incl(e2);
-        float s2 = g + e2;
-        if (j == 0) s2 = -0.0f;
-        const float out2 = fold(s2);
+    float out = 0.0f;
+    for (int round = 0; round < 66; ++round) {
+        out = fold(sc);
         // verify every link bitwise: input of block j must equal the output of block j-1
-        const float prev = wave_prev_lane(out2);
-        const bool ok = (j == 0) || !live || (__float_as_uint(prev) == __float_as_uint(s2));
-        g = s2;
-        out = out2;
+        const float prev = wave_prev_lane(out);
+        const bool ok = (j == 0) || !live || (__float_as_uint(prev) == __float_as_uint(sc));
         if (__all(ok)) break;
+        // corrected inputs under the translation assumption.  With e_j = out_{j-1} - s_j (the mismatch at link j) the
+        // recurrence s'_j = out_{j-1} + (s'_{j-1} - s_{j-1}) unrolls to s'_j = s_j + sum_{i<=j} e_i: another scan.
+        // Block 0's input is exact by construction and round r fixes block r, so the loop terminates, exact.
+        float e = prev - sc;
+        if (j == 0 || !live) e = 0.0f;
+        sc = sc + wave_scan_incl(e);
+        if (j == 0) sc = -0.0f;
     }
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(out), nblk - 1));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(out), nblk - 1));   // the last block's output
 }
 
 // Exact sequential sum of nblk (<= 64) consecutive blocks of blen terms (blen % 4 == 0); block j starts at
 // t + j*stride (16-byte aligned).  Every lane returns the sum.  approx_tot: optional nblk approximate block totals.
-// Blocks of up to kSpecRegQ float4 are pulled into registers once; the folds then run out of VGPRs.
-constexpr int kSpecRegQ = 8;
+// Block lengths of 4..64 terms are compiled as straight-line register code (NQ float4 per lane, pulled from LDS once);
+// other lengths fold out of LDS with the software-pipelined chain.
 template <int NQ>
-__device__ __forceinline__ float chain_regs(float s, const v4f (&r)[kSpecRegQ]) {
-#pragma unroll
-    for (int k = 0; k < NQ; ++k) s = chain4(s, r[k]);
-    return s;
-}
-__device__ __forceinline__ float seq_sum_blocks(const float* t, int nblk, int blen, int stride, const float* approx_tot) {
-    const int nq = blen >> 2;
+__device__ __forceinline__ float seq_sum_blocks_regs(const float* t, int nblk, int stride, const float* approx_tot) {
     const int j = threadIdx.x & 63;
     const bool live = j < nblk;
     const v4f* blk = (const v4f*)(t + (size_t)(live ? j : 0) * stride);
-    const bool in_regs = nq <= kSpecRegQ;        // wave-uniform
-    v4f r[kSpecRegQ];
-    if (in_regs) {
+    v4f r[NQ];
 #pragma unroll
-        for (int k = 0; k < kSpecRegQ; ++k) r[k] = (k < nq) ? blk[k] : v4f{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < NQ; ++k) r[k] = blk[k];
+    float tot = 0.0f;
+    if (approx_tot != nullptr) {
+        if (live) tot = approx_tot[j];
+    } else {
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;      // only a guess: any summation order will do
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) { p0 += r[k].x; p1 += r[k].y; p2 += r[k].z; p3 += r[k].w; }
+        tot = (p0 + p1) + (p2 + p3);
     }
-    // one fold of this lane's block from running sum s: exactly nq float4 (the zero padding of r is never added: -0.0 + 0.0
-    // would flip the sign of an all-zero prefix)
-    auto fold = [&](float s) {
-        if (!in_regs) return seq_chain(s, blk, nq);
-        if (nq == 4) return chain_regs<4>(s, r);
-        if (nq == 8) return chain_regs<8>(s, r);
-        if (nq == 2) return chain_regs<2>(s, r);
-        float acc = s;
+    return spec_sum_lanes(tot, nblk, [&](float s) {
 #pragma unroll
-        for (int k = 0; k < kSpecRegQ; ++k) if (k < nq) acc = chain4(acc, r[k]);
-        return acc;
-    };
-    // approximate block totals: only a guess, any summation order will do
+        for (int k = 0; k < NQ; ++k) s = chain4(s, r[k]);
+        return s;
+    });
+}
+__device__ __forceinline__ float seq_sum_blocks(const float* t, int nblk, int blen, int stride, const float* approx_tot) {
+    const int nq = blen >> 2;
+    if (nq == 4) return seq_sum_blocks_regs<4>(t, nblk, stride, approx_tot);      // dim 1024
+    if (nq == 16) return seq_sum_blocks_regs<16>(t, nblk, stride, approx_tot);    // dim 4096, 64-term blocks
+    if (nq == 1) return seq_sum_blocks_regs<1>(t, nblk, stride, approx_tot);      // softmax rows <= 256
+    if (nq == 2) return seq_sum_blocks_regs<2>(t, nblk, stride, approx_tot);
+    if (nq == 8) return seq_sum_blocks_regs<8>(t, nblk, stride, approx_tot);
+    const int j = threadIdx.x & 63;
+    const bool live = j < nblk;
+    const v4f* blk = (const v4f*)(t + (size_t)(live ? j : 0) * stride);
     float tot = 0.0f;
     if (approx_tot != nullptr) {
         if (live) tot = approx_tot[j];
     } else if (live) {
         float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-        if (in_regs) {
-#pragma unroll
-            for (int k = 0; k < kSpecRegQ; ++k) { p0 += r[k].x; p1 += r[k].y; p2 += r[k].z; p3 += r[k].w; }
-        } else {
-            for (int q = 0; q < nq; ++q) {
-                const v4f v = blk[q];
-                p0 += v.x; p1 += v.y; p2 += v.z; p3 += v.w;
-            }
+        for (int q = 0; q < nq; ++q) {
+            const v4f v = blk[q];
+            p0 += v.x; p1 += v.y; p2 += v.z; p3 += v.w;
         }
         tot = (p0 + p1) + (p2 + p3);
     }
-    return spec_sum_lanes(tot, nblk, fold);
+    return spec_sum_lanes(tot, nblk, [&](float s) { return seq_chain(s, blk, nq); });
 }
 
 // every lane returns the exact sequential sum of the n terms stored (term_index layout) at t
@@ -1448,15 +1393,16 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a) {
 //   * wave w owns timesteps [64w, 64w+64): lane t keeps its K row in registers (HD/4 dwordx4 loads issued at entry, in
 //     flight under the norm) and walks the reference's sequential dot (layers.rs:395-400) against q broadcast from LDS;
 //     the current position's key comes from this kernel (LDS), selected per lane;
-//   * waves 0/1 meanwhile do the QK-RMSNorm + RoPE of q / k (layers.rs:346-372): the HD-term sum of squares is the exact
-//     speculative scan over HD/8 lanes x 8 terms, entirely in registers;
+//   * waves 0/1 meanwhile do the QK-RMSNorm + RoPE of q / k (layers.rs:346-372);
 //   * after ONE barrier on the scores every wave reads them back 4 per lane and does the softmax redundantly (max,
-//     glibc expf, exact sequential sum = speculative scan over 64 lanes x 4 terms) -- no further barrier;
+//     glibc expf, the sequential sum as one chain over LDS for <= 128 timesteps, the speculative scan beyond); every
+//     wave writes the SAME values to the e / p rows, so no barrier separates a wave's own write from its own read;
 //   * the last HD/64 waves own the output elements: V[t][e] arrives by coalesced 4-byte loads (32 timesteps per register
-//     set, double buffered, first two sets requested at entry), the probability of timestep t is pulled into an SGPR by
-//     v_readlane and the chain o += p_t * v_t runs in t order (layers.rs:406-417).
+//     set, double buffered, first two sets requested at entry) and the chain o += p_t * v_t runs in t order
+//     (layers.rs:406-417) with p broadcast from LDS four timesteps per read.
 // Every sum is in the reference's order => bit-identical to k_attn / the CPU path.  Used in both modes (the default mode's
-// tolerance is trivially met).
+// tolerance is trivially met).  Measured cost of the pieces (tools/sum_probe.hip): a dependent v_add 10 cycles, a DPP
+// hop 17, v_readlane + add 23 -- which is why the long chains read their operands from LDS/VGPRs, never cross-lane.
 // ------------------------------------------------------------------------------------------------
 constexpr int kShortMaxT = 256;
 #ifdef Q3_DEV
@@ -1470,10 +1416,12 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
     constexpr int NQ4 = HD / 4;          // float4 per K row
     constexpr int HALF = HD / 2;         // rotate-half pairing (i, i + HD/2)
     constexpr int NVW = HD / 64;         // waves that own output elements (the last NVW of the workgroup)
-    constexpr int NB = HD / 8;           // 8-term blocks of the sum of squares, one lane each
     __shared__ __attribute__((aligned(16))) float q_s[HD];
     __shared__ __attribute__((aligned(16))) float k_s[HD];
-    __shared__ __attribute__((aligned(16))) float att[kShortMaxT];
+    __shared__ __attribute__((aligned(16))) float sq_s[2 * HD];        // squares of raw q | raw k
+    __shared__ __attribute__((aligned(16))) float att[kShortMaxT];     // scores
+    __shared__ __attribute__((aligned(16))) float att_e[kShortMaxT];   // exp(score - max)
+    __shared__ __attribute__((aligned(16))) float att_p[kShortMaxT];   // probabilities
     ATTS_STAMP(0, 0);
 
     const int h = blockIdx.x;
@@ -1490,15 +1438,11 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
     // ---- everything this workgroup will read is requested up front
     const bool is_q = wave == 0, is_k = wave == 1;
     float r_lo = 0.f, r_hi = 0.f, w_lo = 0.f, w_hi = 0.f, rc = 0.f, rs = 0.f;
-    v4f rb0 = {0.f, 0.f, 0.f, 0.f}, rb1 = {0.f, 0.f, 0.f, 0.f};
     if (wave < 2) {
         const float* rawp = is_q ? a.q + (size_t)h * HD : a.k_raw + (size_t)kvh * HD;
         const int i = min(lane, HALF - 1);
         r_lo = rawp[i];
         r_hi = rawp[i + HALF];
-        const int jb = min(lane, NB - 1);
-        rb0 = ((const v4f*)rawp)[2 * jb];
-        rb1 = ((const v4f*)rawp)[2 * jb + 1];
         const float* nw = is_q ? a.q_norm_w : a.k_norm_w;
         w_lo = nw[i];
         w_hi = nw[i + HALF];
@@ -1532,11 +1476,13 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
 
     // ---- waves 0/1: RMSNorm (layers.rs:109-119) + RoPE (layers.rs:173-185) of q / k
     if (wave < 2) {
-        v4f s0, s1;
-        s0.x = rb0.x * rb0.x; s0.y = rb0.y * rb0.y; s0.z = rb0.z * rb0.z; s0.w = rb0.w * rb0.w;
-        s1.x = rb1.x * rb1.x; s1.y = rb1.y * rb1.y; s1.z = rb1.z * rb1.z; s1.w = rb1.w * rb1.w;
-        const float tot = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w));
-        const float ss = spec_sum_lanes(tot, NB, [&](float s) { s = chain4(s, s0); return chain4(s, s1); });
+        float* sq = sq_s + (is_q ? 0 : HD);
+        if (lane < HALF) {
+            sq[lane] = r_lo * r_lo;
+            sq[lane + HALF] = r_hi * r_hi;
+        }
+        wave_lds_sync();
+        const float ss = seq_chain(-0.0f, (const v4f*)sq, NQ4);      // strict left fold, layers.rs:113
         const float f = 1.0f / sqrtf(ss / (float)HD + kEps);
         if (lane < HALF) {
             const float xv = w_lo * (f * r_lo);
@@ -1602,27 +1548,36 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
     e4.y = t4 + 1 < np ? e4.y : 0.0f;
     e4.z = t4 + 2 < np ? e4.z : 0.0f;
     e4.w = t4 + 3 < np ? e4.w : 0.0f;
-    const float etot = (e4.x + e4.y) + (e4.z + e4.w);
-    const float sum = spec_sum_lanes(etot, (np + 3) >> 2, [&](float s) { return chain4(s, e4); });
+    float sum;
+    if (np <= 128) {
+        // one chain over the (zero padded) row: np adds of 10 cycles, operands streamed from LDS as float4
+        ((v4f*)att_e)[lane] = e4;                         // every wave writes the same values
+        wave_lds_sync();
+        sum = seq_chain(-0.0f, (const v4f*)att_e, (np + 3) >> 2);
+    } else {
+        const float etot = (e4.x + e4.y) + (e4.z + e4.w);
+        sum = spec_sum_lanes(etot, (np + 3) >> 2, [&](float s) { return chain4(s, e4); });
+    }
     const float inv = 1.0f / sum;
-    int p4[4];
-    p4[0] = __float_as_int(e4.x * inv);
-    p4[1] = __float_as_int(e4.y * inv);
-    p4[2] = __float_as_int(e4.z * inv);
-    p4[3] = __float_as_int(e4.w * inv);
+    v4f p4;
+    p4.x = e4.x * inv; p4.y = e4.y * inv; p4.z = e4.z * inv; p4.w = e4.w * inv;
+    ((v4f*)att_p)[lane] = p4;                             // identical in every wave; 0 past the context
+    wave_lds_sync();
     ATTS_STAMP(5, kWG - 64);
 
     // ---- xb = sum_t att[t] * V[t], one chain per output element in t order          layers.rs:406-417
     if (is_v) {
         float o = 0.0f;
         auto fold_chunk = [&](const float (&R)[32], int c) {
+            const v4f* pp = (const v4f*)att_p + 8 * c;
 #pragma unroll
-            for (int u = 0; u < 32; ++u) {
-                // probability of timestep 32c+u sits in lane 8c + u/4, component u%4 (0 past the context)
-                const float pv = __int_as_float(__builtin_amdgcn_readlane(p4[u & 3], 8 * c + (u >> 2)));
-                const float vv = (32 * c + u < np) ? R[u] : 0.0f;
-                const float pr = pv * vv;
-                o = o + pr;
+            for (int u4 = 0; u4 < 8; ++u4) {
+                const v4f pv = pp[u4];                    // probabilities of timesteps 32c+4u4 .. +3 (0 past the context)
+                const int tb = 32 * c + 4 * u4;
+                float pr = pv.x * (tb + 0 < np ? R[4 * u4 + 0] : 0.0f); o = o + pr;
+                pr = pv.y * (tb + 1 < np ? R[4 * u4 + 1] : 0.0f); o = o + pr;
+                pr = pv.z * (tb + 2 < np ? R[4 * u4 + 2] : 0.0f); o = o + pr;
+                pr = pv.w * (tb + 3 < np ? R[4 * u4 + 3] : 0.0f); o = o + pr;
             }
         };
         for (int c = 0; 32 * c < np; c += 2) {

@@ -1,0 +1,124 @@
+// Developer probe: shader-cycle cost of the cross-lane primitives the exact sums are built from, and of the whole
+// exact sequential sum on realistic data.  One 256-thread workgroup (one wave per SIMD), like the engine's kernels.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o tools/sum_probe tools/sum_probe.hip && tools/sum_probe
+#include "../qwen3-rs_amd/csrc/q3_kernels.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <math.h>
+#include <vector>
+using namespace q3;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("ERR %s: %s\n", #x, hipGetErrorString(e_)); exit(1);} } while (0)
+
+__device__ __forceinline__ unsigned long long now() { return __builtin_amdgcn_s_memtime(); }
+
+// mode: which primitive; every primitive is applied 64 times in a dependent chain
+__global__ __launch_bounds__(256) void k_prim(float* out, unsigned long long* cyc, const float* in, int mode) {
+    float v = in[threadIdx.x], t = in[256 + threadIdx.x];
+    __builtin_amdgcn_s_barrier();
+    const unsigned long long t0 = now();
+    if (mode == 0) { for (int i = 0; i < 64; ++i) v = v + t; }
+    else if (mode == 1) { for (int i = 0; i < 64; ++i) v = wave_scan_incl(v) * 0.25f; }
+    else if (mode == 2) { for (int i = 0; i < 64; ++i) v = wave_prev_lane(v) + t; }
+    else if (mode == 3) { for (int i = 0; i < 64; ++i) v = dpp_f<0x114>(v) + t; }
+    else if (mode == 4) { for (int i = 0; i < 64; ++i) v = v + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), i)); }
+    else if (mode == 5) { for (int i = 0; i < 64; ++i) v = dpp_f<0x142>(v) + t; }
+    else if (mode == 6) { for (int i = 0; i < 64; ++i) v = __shfl_up(v, 1) + t; }
+    else if (mode == 7) { for (int i = 0; i < 64; ++i) { const unsigned long long b = __ballot(v > t); v = v + (float)__builtin_ctzll(b | 0x8000000000000000ull); } }
+    else if (mode == 8) { for (int i = 0; i < 64; ++i) v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)) + t; }
+    const unsigned long long t1 = now();
+    out[threadIdx.x] = v;
+    if (threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+// the plain iteration (round r fixes block r), for comparison with spec_sum_lanes
+template <class Fold>
+__device__ __forceinline__ float iter_sum_lanes(float tot, int nblk, Fold fold, int* rounds) {
+    const int j = threadIdx.x & 63;
+    const bool live = j < nblk;
+    if (!live) tot = 0.0f;
+    float g = wave_prev_lane(wave_scan_incl(tot));
+    if (j == 0) g = -0.0f;
+    float out = fold(g);
+    int r = 0;
+    for (int round = 0; round < 65; ++round) {
+        float e = wave_prev_lane(out) - g;
+        if (j == 0 || !live) e = 0.0f;
+        e = wave_scan_incl(e);
+        float sc = g + e;
+        if (j == 0) sc = -0.0f;
+        const float out2 = fold(sc);
+        const float prev = wave_prev_lane(out2);
+        const bool ok = (j == 0) || !live || (__float_as_uint(prev) == __float_as_uint(sc));
+        g = sc; out = out2; ++r;
+        if (__all(ok)) break;
+    }
+    *rounds = r;
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(out), nblk - 1));
+}
+
+// variant: 0 = engine's seq_sum_terms (candidate scheme), 1 = plain iteration with blocks of B4*4 terms in registers
+template <int B4>
+__global__ __launch_bounds__(256) void k_sum(float* out, unsigned long long* cyc, int* rounds, const float* x, int n, int variant) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sq = (float*)smem;
+    const int tid = threadIdx.x;
+    if (variant == 0) { for (int i = tid; i < n; i += 256) sq[term_index(i, n)] = x[i] * x[i]; }
+    else { for (int i = tid; i < n; i += 256) sq[i] = x[i] * x[i]; }
+    __syncthreads();
+    const unsigned long long t0 = now();
+    float s; int r = 0;
+    if (variant == 0) s = seq_sum_terms(sq, n);
+    else {
+        const int lane = tid & 63, nblk = n / (4 * B4);
+        v4f rr[B4];
+        const v4f* blk = (const v4f*)(sq + (lane < nblk ? lane : 0) * 4 * B4);
+#pragma unroll
+        for (int k = 0; k < B4; ++k) rr[k] = blk[k];
+        float p = 0.f;
+#pragma unroll
+        for (int k = 0; k < B4; ++k) p += (rr[k].x + rr[k].y) + (rr[k].z + rr[k].w);
+        s = iter_sum_lanes(p, nblk, [&](float a) {
+#pragma unroll
+            for (int k = 0; k < B4; ++k) a = chain4(a, rr[k]);
+            return a; }, &r);
+    }
+    const unsigned long long t1 = now();
+    out[tid] = s;
+    if (tid == 0) { cyc[0] = t1 - t0; rounds[0] = r; }
+}
+
+int main() {
+    float *din, *dout; unsigned long long* dcyc; int* drounds;
+    const int n = 1024;
+    CK(hipMalloc(&din, 4 * 16384)); CK(hipMalloc(&dout, 4 * 256)); CK(hipMalloc(&dcyc, 8)); CK(hipMalloc(&drounds, 4));
+    std::vector<float> h(16384);
+    srand(1);
+    auto gauss = []() { double u = (rand() + 1.0) / (RAND_MAX + 2.0), v = (rand() + 1.0) / (RAND_MAX + 2.0); return (float)(sqrt(-2 * log(u)) * cos(6.283185307 * v)); };
+    const char* names[] = {"v_add chain", "wave_scan_incl (6 dpp adds)+mul", "wave_prev_lane (wave_shr:1)+add", "row_shr:4 dpp + add", "v_readlane(const)+add", "row_bcast:15 dpp + add", "__shfl_up(1)+add (ds_bpermute)", "ballot+ctz+cvt+add", "readlane(v,63)+add (dependent)"};
+    for (int i = 0; i < 16384; ++i) h[i] = gauss();
+    CK(hipMemcpy(din, h.data(), 4 * 16384, hipMemcpyHostToDevice));
+    for (int mode = 0; mode < 9; ++mode) {
+        unsigned long long c = 0;
+        for (int rep = 0; rep < 3; ++rep) { hipLaunchKernelGGL(k_prim, 1, 256, 0, 0, dout, dcyc, din, mode); CK(hipDeviceSynchronize()); }
+        CK(hipMemcpy(&c, dcyc, 8, hipMemcpyDeviceToHost));
+        printf("%-36s %7.1f cycles per step\n", names[mode], c / 64.0);
+    }
+    for (int nn : {1024, 2560, 4096}) {
+        for (int trial = 0; trial < 4; ++trial) {
+            const float scale = trial == 0 ? 1.0f : (trial == 1 ? 0.05f : (trial == 2 ? 7.0f : 1.0f));
+            for (int i = 0; i < nn; ++i) h[i] = gauss() * scale * (trial == 3 ? expf(gauss()) : 1.0f);
+            CK(hipMemcpy(din, h.data(), 4 * nn, hipMemcpyHostToDevice));
+            float ref = -0.0f; for (int i = 0; i < nn; ++i) { float q = h[i] * h[i]; ref = ref + q; }
+            auto run = [&](const char* what, auto kern, int variant) {
+                unsigned long long c = 0; int r = 0; float s = 0;
+                for (int rep = 0; rep < 3; ++rep) { hipLaunchKernelGGL(kern, 1, 256, 4 * (nn + 1024), 0, dout, dcyc, drounds, din, nn, variant); CK(hipDeviceSynchronize()); }
+                CK(hipMemcpy(&c, dcyc, 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&r, drounds, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&s, dout, 4, hipMemcpyDeviceToHost));
+                printf("n=%5d trial %d  %-34s %6llu cycles  rounds %2d  %s\n", nn, trial, what, c, r, s == ref ? "exact" : "WRONG");
+            };
+            run("engine seq_sum_terms", k_sum<4>, 0);
+            if (nn == 1024) { run("plain iteration, 64 x 16 terms", k_sum<4>, 1); run("plain iteration, 32 x 32 terms", k_sum<8>, 1); run("plain iteration, 16 x 64 terms", k_sum<16>, 1); }
+            if (nn == 4096) { run("plain iteration, 64 x 64 terms", k_sum<16>, 1); }
+        }
+    }
+    return 0;
+}
