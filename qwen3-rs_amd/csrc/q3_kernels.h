@@ -134,7 +134,9 @@ __device__ __constant__ unsigned long long kExp2Tab[32] = {
     0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
     0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
 
-__device__ __forceinline__ float q3_expf(float x) {
+// `tab`: the 32-entry exp2 table -- kExp2Tab in constant memory (a dependent global load in the middle of the
+// evaluation), or a copy the kernel staged in LDS (latency-critical single-wave phases).
+__device__ __forceinline__ float q3_expf_t(float x, const unsigned long long* tab) {
     const unsigned ux = __float_as_uint(x);
     const unsigned abstop = (ux >> 20) & 0x7ffu;
     if (abstop >= 0x42bu) {  // |x| >= 88.0f
@@ -154,7 +156,7 @@ __device__ __forceinline__ float q3_expf(float x) {
     const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
     kd -= kShift;
     const double r = z - kd;
-    const unsigned long long t = kExp2Tab[ki & 31u] + (ki << 47);
+    const unsigned long long t = tab[ki & 31u] + (ki << 47);
     const double s = __longlong_as_double((long long)t);
     z = kC0 * r + kC1;
     const double r2 = r * r;
@@ -163,6 +165,7 @@ __device__ __forceinline__ float q3_expf(float x) {
     y = y * s;
     return (float)y;
 }
+__device__ __forceinline__ float q3_expf(float x) { return q3_expf_t(x, kExp2Tab); }
 
 // f32::total_cmp key (sampler.rs:57-59): unsigned order of the key == IEEE total order
 __device__ __forceinline__ unsigned total_order_key(float f) {
@@ -247,13 +250,14 @@ struct GemvSmem {
     float* xf;
     float* term;
     float* red;
+    unsigned long long* etab;   // EPI_SWIGLU: LDS copy of the exp2 table (32 x 8 B)
 };
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~size_t(15); }
 __host__ __device__ inline size_t gemv_smem_bytes(int n, int group, int vr, bool stage_f32) {
     size_t b = align16((size_t)n) + align16(4 * (size_t)(n / group));
     if (stage_f32) b += align16(4 * (size_t)term_floats(n));
     b += align16(4 * (size_t)kWaves * vr * (n / group));
-    b += 128 * 4;
+    b += 128 * 4 + 32 * 8;
     return b;
 }
 __device__ __forceinline__ GemvSmem gemv_carve(char* base, int n, int group, int vr, bool stage_f32) {
@@ -267,6 +271,7 @@ __device__ __forceinline__ GemvSmem gemv_carve(char* base, int n, int group, int
     s.term = (float*)base;
     base += align16(4 * (size_t)kWaves * vr * (n / group));
     s.red = (float*)base;
+    s.etab = (unsigned long long*)(base + 128 * 4);
     return s;
 }
 
@@ -926,7 +931,7 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
             } else if (EPI == EPI_SWIGLU) {
                 float u = up;
                 if constexpr (FIN == 0) u = ordered_row_sum(term + (lane + HU) * ng, ng);
-                const float den = 1.0f + q3_expf(-acc);   // layers.rs:472-475
+                const float den = 1.0f + q3_expf_t(-acc, sm.etab);   // layers.rs:472-475
                 const float sw = acc * (1.0f / den);
                 rs.out[lane] = sw * u;
             } else if (EPI == EPI_LOGITS) {
@@ -948,6 +953,8 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
     Tile<RU, JU> TA, TB;
     RowSrc RA, RB;
     ProRegs<PRO> pr;
+    unsigned long long etv = 0ull;
+    if (EPI == EPI_SWIGLU && threadIdx.x < 32) etv = kExp2Tab[threadIdx.x];   // oldest load: retires first (vmcnt is in order)
     gemv_prologue_issue<PRO>(a, pr);          // activation / norm-weight loads go out first ...
     __builtin_amdgcn_sched_barrier(0);        // (pin the issue order: vmcnt retires in order)
     RA = batch_rows(min(cb, nb - 1));         // (idle waves re-read a valid batch; nothing is stored)
@@ -958,8 +965,10 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
         for (int i = threadIdx.x; i < (a.n >> 2); i += kWG) ((int*)sm.xq)[i] = 0x01010101;
         for (int i = threadIdx.x; i < a.n / a.group; i += kWG) sm.xs[i] = 1.0f;
         __syncthreads();
-    } else
+    } else {
+    if (EPI == EPI_SWIGLU && threadIdx.x < 32) sm.etab[threadIdx.x] = etv;   // visible after the prologue's barrier
     gemv_prologue_finish<PRO, LPG_T>(a, sm, pr);     // ... and norm + quantize run under the weight loads
+    }
     stamp(a, 2);
     if (any && !Q3_DEV_ABLATE(a, 2)) {
         for (;;) {
@@ -1422,6 +1431,7 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float att[kShortMaxT];     // scores
     __shared__ __attribute__((aligned(16))) float att_e[kShortMaxT];   // exp(score - max)
     __shared__ __attribute__((aligned(16))) float att_p[kShortMaxT];   // probabilities
+    __shared__ unsigned long long etab[32];                            // exp2 table of q3_expf, staged once
     ATTS_STAMP(0, 0);
 
     const int h = blockIdx.x;
@@ -1436,6 +1446,8 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
     const float* vbase = a.value_cache + (size_t)kvh * HD;
 
     // ---- everything this workgroup will read is requested up front
+    unsigned long long etv = 0ull;
+    if (tid >= kWG - 32) etv = kExp2Tab[tid - (kWG - 32)];
     const bool is_q = wave == 0, is_k = wave == 1;
     float r_lo = 0.f, r_hi = 0.f, w_lo = 0.f, w_hi = 0.f, rc = 0.f, rs = 0.f;
     if (wave < 2) {
@@ -1473,6 +1485,7 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
         if (np > 32) v_issue(vb, 1);
     }
     ATTS_STAMP(1, 0);
+    if (tid >= kWG - 32) etab[tid - (kWG - 32)] = etv;
 
     // ---- waves 0/1: RMSNorm (layers.rs:109-119) + RoPE (layers.rs:173-185) of q / k
     if (wave < 2) {
@@ -1512,17 +1525,15 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
     const float scale = 1.0f / sqrtf((float)HD);
     float sc = -__builtin_inff();
     if (wave_has_t) {
-        const bool is_pos = t == pos;
+        if (t == pos) {                                   // one lane of one wave: the current position's key is in LDS
+#pragma unroll
+            for (int i = 0; i < NQ4; ++i) kr[i] = ((const v4f*)k_s)[i];
+        }
         float dot = -0.0f;
 #pragma unroll
         for (int i = 0; i < NQ4; ++i) {
             const v4f qv = ((const v4f*)q_s)[i];
-            const v4f kn = ((const v4f*)k_s)[i];
-            v4f kk = kr[i];
-            kk.x = is_pos ? kn.x : kk.x;
-            kk.y = is_pos ? kn.y : kk.y;
-            kk.z = is_pos ? kn.z : kk.z;
-            kk.w = is_pos ? kn.w : kk.w;
+            const v4f kk = kr[i];
             float p = qv.x * kk.x; dot = dot + p;
             p = qv.y * kk.y; dot = dot + p;
             p = qv.z * kk.z; dot = dot + p;
@@ -1534,50 +1545,48 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
     __syncthreads();
     ATTS_STAMP(4, 0);
 
-    // ---- softmax (layers.rs:495-506), redundantly in every wave: lane l holds timesteps 4l .. 4l+3
+    // ---- softmax (layers.rs:495-506): the max in every wave (4 scores per lane), exp of the wave's own timesteps
     const v4f s4 = ((const v4f*)att)[lane];
     float m = fmaxf(fmaxf(s4.x, s4.y), fmaxf(s4.z, s4.w));
     m = group_max_f32(m, 64);
-    const int t4 = 4 * lane;
-    v4f e4;
-    e4.x = q3_expf(t4 + 0 < np ? s4.x - m : 0.0f);
-    e4.y = q3_expf(t4 + 1 < np ? s4.y - m : 0.0f);
-    e4.z = q3_expf(t4 + 2 < np ? s4.z - m : 0.0f);
-    e4.w = q3_expf(t4 + 3 < np ? s4.w - m : 0.0f);
-    e4.x = t4 + 0 < np ? e4.x : 0.0f;                    // +0.0 past the context: leaves every partial sum unchanged
-    e4.y = t4 + 1 < np ? e4.y : 0.0f;
-    e4.z = t4 + 2 < np ? e4.z : 0.0f;
-    e4.w = t4 + 3 < np ? e4.w : 0.0f;
-    float sum;
-    if (np <= 128) {
-        // one chain over the (zero padded) row: np adds of 10 cycles, operands streamed from LDS as float4
-        ((v4f*)att_e)[lane] = e4;                         // every wave writes the same values
-        wave_lds_sync();
-        sum = seq_chain(-0.0f, (const v4f*)att_e, (np + 3) >> 2);
-    } else {
-        const float etot = (e4.x + e4.y) + (e4.z + e4.w);
-        sum = spec_sum_lanes(etot, (np + 3) >> 2, [&](float s) { return chain4(s, e4); });
+    float ev = 0.0f;
+    if (wave_has_t) {
+        ev = q3_expf_t(t < np ? sc - m : 0.0f, etab);
+        ev = t < np ? ev : 0.0f;                          // +0.0 past the context: leaves every partial sum unchanged
     }
-    const float inv = 1.0f / sum;
-    v4f p4;
-    p4.x = e4.x * inv; p4.y = e4.y * inv; p4.z = e4.z * inv; p4.w = e4.w * inv;
-    ((v4f*)att_p)[lane] = p4;                             // identical in every wave; 0 past the context
-    wave_lds_sync();
+    att_e[t] = ev;
+    __syncthreads();
     ATTS_STAMP(5, kWG - 64);
 
-    // ---- xb = sum_t att[t] * V[t], one chain per output element in t order          layers.rs:406-417
+    // ---- the waves that own output elements: softmax denominator, probabilities, then
+    //      xb = sum_t att[t] * V[t], one chain per output element in t order          layers.rs:406-417
     if (is_v) {
+        const v4f e4 = ((const v4f*)att_e)[lane];
+        float sum;
+        if (np <= 128) {
+            // one chain over the (zero padded) row: np adds of 10 cycles, operands streamed from LDS as float4
+            sum = seq_chain(-0.0f, (const v4f*)att_e, (np + 3) >> 2);
+        } else {
+            const float etot = (e4.x + e4.y) + (e4.z + e4.w);
+            sum = spec_sum_lanes(etot, (np + 3) >> 2, [&](float s) { return chain4(s, e4); });
+        }
+        const float inv = 1.0f / sum;
+        v4f p4;
+        p4.x = e4.x * inv; p4.y = e4.y * inv; p4.z = e4.z * inv; p4.w = e4.w * inv;
+        ((v4f*)att_p)[lane] = p4;                         // both V waves write the same values; 0 past the context
+        wave_lds_sync();
         float o = 0.0f;
         auto fold_chunk = [&](const float (&R)[32], int c) {
             const v4f* pp = (const v4f*)att_p + 8 * c;
 #pragma unroll
             for (int u4 = 0; u4 < 8; ++u4) {
-                const v4f pv = pp[u4];                    // probabilities of timesteps 32c+4u4 .. +3 (0 past the context)
-                const int tb = 32 * c + 4 * u4;
-                float pr = pv.x * (tb + 0 < np ? R[4 * u4 + 0] : 0.0f); o = o + pr;
-                pr = pv.y * (tb + 1 < np ? R[4 * u4 + 1] : 0.0f); o = o + pr;
-                pr = pv.z * (tb + 2 < np ? R[4 * u4 + 2] : 0.0f); o = o + pr;
-                pr = pv.w * (tb + 3 < np ? R[4 * u4 + 3] : 0.0f); o = o + pr;
+                // probabilities of timesteps 32c+4u4 .. +3; past the context p = +0.0 and R holds the (finite) row pos
+                // again, so the term is +-0.0 and o + (+-0.0) == o (o starts from +0.0 and is never -0.0)
+                const v4f pv = pp[u4];
+                float pr = pv.x * R[4 * u4 + 0]; o = o + pr;
+                pr = pv.y * R[4 * u4 + 1]; o = o + pr;
+                pr = pv.z * R[4 * u4 + 2]; o = o + pr;
+                pr = pv.w * R[4 * u4 + 3]; o = o + pr;
             }
         };
         for (int c = 0; 32 * c < np; c += 2) {

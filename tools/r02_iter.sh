@@ -14,3 +14,5 @@ except Exception as e: print("bench parse failed", e)
 PY
 Q3_STAMPS=1 Q3_STRICT=1 Q3_HIP_LIB=qwen3-rs_amd/libqwen3_hip_dev.so Q3_NTOK=32 timeout 300 python tools/gen_loop.py > $out/stamps.log 2>&1
 tail -9 $out/stamps.log
+for w in 2 3; do echo "Q3_WG_PER_CU_SMALL=$w"; Q3_WG_PER_CU_SMALL=$w Q3_STRICT=1 Q3_NTOK=128 timeout 300 python tools/gen_loop.py 2>&1 | tail -1; done
+echo "default, 128 tok"; Q3_STRICT=1 Q3_NTOK=128 timeout 300 python tools/gen_loop.py 2>&1 | tail -1
