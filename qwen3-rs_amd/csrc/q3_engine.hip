@@ -135,34 +135,38 @@ struct Launch {
 };
 
 // tile shapes instantiated: group 64 (every listed model) gets the full set, other group sizes a
-// single-row-run fallback (RU = 1, or 2 for SwiGLU).  FIN = 1 (DPP-chain fold of the group terms, latency-bound
-// launches) exists for group 64.
-template <int PRO, int EPI, int LPG_T, int RU, int FIN = 0>
+// single-row-run fallback (RU = 1, or 2 for SwiGLU).  Variants (k_gemv FIN / PF): FIN = DPP-chain fold of the group terms
+// (group 64, rows a whole number of tiles), PF = second tile requested before the prologue (streaming launches).
+// Instantiated: (FIN,PF) = (0,0) everywhere; (1,0) and (1,1) for the layer kernels; (0,1) for the classifier.
+template <int PRO, int EPI, int LPG_T, int RU, int FIN = 0, int PF = 0>
 GemvFn pick_ju(int JU) {
-    if (JU == 1) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 1, FIN>;
-    if (JU == 2) { if constexpr (RU <= 4) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 2, FIN>; }
-    if (JU == 3) { if constexpr (RU <= 2) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 3, FIN>; }
-    if (JU == 4) { if constexpr (RU <= 2) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 4, FIN>; }
+    if (JU == 1) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 1, FIN, PF>;
+    if (JU == 2) { if constexpr (RU <= 4) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 2, FIN, PF>; }
+    if (JU == 3) { if constexpr (RU <= 2) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 3, FIN, PF>; }
+    if (JU == 4) { if constexpr (RU <= 2) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 4, FIN, PF>; }
+    return nullptr;
+}
+template <int PRO, int EPI, int FIN, int PF>
+GemvFn pick_ru64(int RU, int JU) {
+    constexpr bool sw = (EPI == EPI_SWIGLU);
+    if (RU == 8) return pick_ju<PRO, EPI, 4, 8, FIN, PF>(JU);
+    if (RU == 4) return pick_ju<PRO, EPI, 4, 4, FIN, PF>(JU);
+    if (RU == 2) return pick_ju<PRO, EPI, 4, 2, FIN, PF>(JU);
+    if constexpr (!sw) { if (RU == 1) return pick_ju<PRO, EPI, 4, 1, FIN, PF>(JU); }
     return nullptr;
 }
 template <int PRO, int EPI>
-GemvFn pick(int G, int RU, int JU, int FIN = 0) {
+GemvFn pick(int G, int RU, int JU, int FIN = 0, int PF = 0) {
     constexpr bool sw = (EPI == EPI_SWIGLU);
     if (G == 64) {
-        if constexpr (EPI != EPI_LOGITS) {
-            if (FIN) {
-                if (RU == 8) return pick_ju<PRO, EPI, 4, 8, 1>(JU);
-                if (RU == 4) return pick_ju<PRO, EPI, 4, 4, 1>(JU);
-                if (RU == 2) return pick_ju<PRO, EPI, 4, 2, 1>(JU);
-                if constexpr (!sw) { if (RU == 1) return pick_ju<PRO, EPI, 4, 1, 1>(JU); }
-                return nullptr;
-            }
+        if constexpr (EPI == EPI_LOGITS) {
+            if (PF) return pick_ru64<PRO, EPI, 0, 1>(RU, JU);
+            return pick_ru64<PRO, EPI, 0, 0>(RU, JU);
+        } else {
+            if (FIN && PF) return pick_ru64<PRO, EPI, 1, 1>(RU, JU);
+            if (FIN) return pick_ru64<PRO, EPI, 1, 0>(RU, JU);
+            return pick_ru64<PRO, EPI, 0, 0>(RU, JU);
         }
-        if (RU == 8) return pick_ju<PRO, EPI, 4, 8>(JU);
-        if (RU == 4) return pick_ju<PRO, EPI, 4, 4>(JU);
-        if (RU == 2) return pick_ju<PRO, EPI, 4, 2>(JU);
-        if constexpr (!sw) { if (RU == 1) return pick_ju<PRO, EPI, 4, 1>(JU); }
-        return nullptr;
     }
     if constexpr (sw) { if (RU == 2) return pick_ju<PRO, EPI, 0, 2>(JU); }
     else { if (RU == 1) return pick_ju<PRO, EPI, 0, 1>(JU); }
@@ -257,10 +261,11 @@ void launch_one(const Launch& L, q3_engine* e) {
 // Tile shape + grid for one GEMV launch.  units = output rows (SwiGLU: hidden units, each 2 weight rows).
 // JU follows the row length (1 KiB chunks per row); RU is the largest row count per wave batch that keeps
 // every wave of the grid busy and minimises max rows per wave; larger kernels grid-stride over batches.
-struct GemvShape { int RU, JU; unsigned grid; int FIN; };
+struct GemvShape { int RU, JU; unsigned grid; int FIN, PF; };
 GemvShape plan_gemv(int units, int n, int G, bool swiglu, int row_align, int n_cu, int wg_per_cu, bool allow_fin = true) {
     GemvShape g;
     g.FIN = 0;
+    g.PF = 0;
     // launches that stream >= 16 MB are bandwidth- rather than latency-bound: give them a second workgroup per CU
     const size_t launch_bytes = (size_t)units * (swiglu ? 2 : 1) * (size_t)n;
     if (launch_bytes >= (16u << 20) && wg_per_cu < 2) wg_per_cu = 2;
@@ -282,8 +287,9 @@ GemvShape plan_gemv(int units, int n, int G, bool swiglu, int row_align, int n_c
     if (force_ju >= 1 && force_ju <= 4) g.JU = force_ju;
     const int ru_max = 8 / g.JU, ru_min = swiglu ? 2 : 1;
     const int waves = n_cu * wg_per_cu * kWaves;
-    // latency-bound launches whose rows are a whole number of tiles fold the group terms in registers (k_gemv FIN = 1)
-    if (allow_fin && env_int("Q3_GEMV_FIN", 1) && G == 64 && nchunks % (64 * g.JU) == 0 && launch_bytes < (16u << 20)) g.FIN = 1;
+    // rows that are a whole number of tiles fold the group terms in registers (k_gemv FIN = 1)
+    if (allow_fin && env_int("Q3_GEMV_FIN", 1) && G == 64 && nchunks % (64 * g.JU) == 0 &&
+        launch_bytes < ((size_t)env_int("Q3_GEMV_FIN_MAXMB", 1 << 20) << 20)) g.FIN = 1;
     int best_ru = ru_min;
     long best_cost = -1;
     for (int ru = ru_max; ru >= ru_min; ru >>= 1) {
@@ -304,6 +310,9 @@ GemvShape plan_gemv(int units, int n, int G, bool swiglu, int row_align, int n_c
     if (grid > (long)n_cu * wg_per_cu) grid = (long)n_cu * wg_per_cu;
     if (grid < 1) grid = 1;
     g.grid = (unsigned)grid;
+    // streaming launches (every wave owns at least two tiles): request the second tile before the prologue too
+    const long njt_h = (nj + g.JU - 1) / g.JU;
+    if (env_int("Q3_GEMV_PF", 1) && G == 64 && nb * njt_h >= 2 * grid * kWaves && (g.FIN || !allow_fin)) g.PF = 1;
     return g;
 }
 
@@ -484,7 +493,7 @@ int q3_engine::build_plan() {
     const int dim = cfg.dim, L = cfg.n_layers, hd = cfg.head_dim, V = cfg.vocab_size, H = cfg.hidden_dim;
     const int G = cfg.group_size, ahd = cfg.n_heads * hd, kvd = cfg.n_kv_heads * hd, S = cfg.seq_len;
     const int strict = (flags & Q3_FLAG_FAST) ? 0 : 1;
-    const int small_cap = env_int("Q3_WG_PER_CU_SMALL", 1);
+    const int small_cap = env_int("Q3_WG_PER_CU_SMALL", 2);   // two workgroups per CU: half the rows (and fold chains) per wave
     const int big_cap = env_int("Q3_WG_PER_CU_LMHEAD", 4);
     const int att_lds_max = env_int("Q3_ATT_LDS_MAX", 4096);
 
@@ -535,9 +544,9 @@ int q3_engine::build_plan() {
                 a.emb_q = tok.q;
                 a.emb_s = tok.s;
                 a.x_out = d_x;
-                Ln.fn = pick<PRO_EMBED_NORM, EPI_QKV>(G, gs.RU, gs.JU, gs.FIN);
+                Ln.fn = pick<PRO_EMBED_NORM, EPI_QKV>(G, gs.RU, gs.JU, gs.FIN, gs.PF);
             } else {
-                Ln.fn = pick<PRO_NORM, EPI_QKV>(G, gs.RU, gs.JU, gs.FIN);
+                Ln.fn = pick<PRO_NORM, EPI_QKV>(G, gs.RU, gs.JU, gs.FIN, gs.PF);
             }
             a.vr = gs.RU;
             Ln.grid = gs.grid;
@@ -588,7 +597,7 @@ int q3_engine::build_plan() {
             a.total_rows = dim;
             a.in = d_xb;
             const GemvShape gs = plan_gemv(dim, ahd, G, false, 1, n_cu, small_cap);
-            Ln.fn = pick<PRO_QUANT, EPI_RESID>(G, gs.RU, gs.JU, gs.FIN);
+            Ln.fn = pick<PRO_QUANT, EPI_RESID>(G, gs.RU, gs.JU, gs.FIN, gs.PF);
             a.vr = gs.RU;
             Ln.grid = gs.grid;
             Ln.smem = gemv_smem_bytes(ahd, G, a.vr, false);
@@ -608,7 +617,7 @@ int q3_engine::build_plan() {
             a.norm_w = rms_ffn + (size_t)l * dim;
             a.in = d_x;
             const GemvShape gs = plan_gemv(H, dim, G, true, 1, n_cu, small_cap);
-            Ln.fn = pick<PRO_NORM, EPI_SWIGLU>(G, gs.RU, gs.JU, gs.FIN);
+            Ln.fn = pick<PRO_NORM, EPI_SWIGLU>(G, gs.RU, gs.JU, gs.FIN, gs.PF);
             a.vr = gs.RU;
             Ln.grid = gs.grid;
             Ln.smem = gemv_smem_bytes(dim, G, a.vr, true);
@@ -626,7 +635,7 @@ int q3_engine::build_plan() {
             a.total_rows = dim;
             a.in = d_hb;
             const GemvShape gs = plan_gemv(dim, H, G, false, 1, n_cu, small_cap);
-            Ln.fn = pick<PRO_QUANT, EPI_RESID>(G, gs.RU, gs.JU, gs.FIN);
+            Ln.fn = pick<PRO_QUANT, EPI_RESID>(G, gs.RU, gs.JU, gs.FIN, gs.PF);
             a.vr = gs.RU;
             Ln.grid = gs.grid;
             Ln.smem = gemv_smem_bytes(H, G, a.vr, false);
@@ -651,7 +660,7 @@ int q3_engine::build_plan() {
         HIP_TRY(hipMalloc((void**)&d_argmax_slots, 8 * (size_t)n_argmax_slots));
         HIP_TRY(hipMemset(d_argmax_slots, 0, 8 * (size_t)n_argmax_slots));
         a.argmax_slots = d_argmax_slots;
-        Ln.fn = pick<PRO_NORM, EPI_LOGITS>(G, gs.RU, gs.JU);
+        Ln.fn = pick<PRO_NORM, EPI_LOGITS>(G, gs.RU, gs.JU, 0, gs.PF);
         a.vr = gs.RU;
         Ln.grid = gs.grid;
         Ln.smem = gemv_smem_bytes(dim, G, a.vr, true);
@@ -1140,7 +1149,7 @@ int q3_op_matmul(float* xout, const int8_t* xq, const float* xs, const int8_t* w
     a.vr = gs.RU;
     const unsigned grid = gs.grid;
     const size_t smem = gemv_smem_bytes((int)n, (int)group_size, a.vr, false);
-    GemvFn fn = pick<PRO_PREQ, EPI_STORE>((int)group_size, gs.RU, gs.JU, gs.FIN);
+    GemvFn fn = pick<PRO_PREQ, EPI_STORE>((int)group_size, gs.RU, gs.JU, gs.FIN, gs.PF);
     if (!fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel for tile %dx%d", gs.RU, gs.JU);
     if ((rc = set_max_smem((const void*)fn, smem))) return rc;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kWG), smem, 0, a);
@@ -1307,8 +1316,8 @@ int q3_dev_bench_gemv(size_t n, size_t d, size_t group_size, int wg_per_cu, int 
         const long cap = (long)prop.multiProcessorCount * (wg_per_cu > 0 ? wg_per_cu : 4);
         gs.grid = (unsigned)(grid > cap ? cap : grid);
     }
-    if (ru > 0 || ju > 0) gs.FIN = 0;
-    GemvFn fn = pick<PRO_PREQ, EPI_STORE>((int)group_size, gs.RU, gs.JU, gs.FIN);
+    if (ru > 0 || ju > 0) { gs.FIN = 0; gs.PF = 0; }
+    GemvFn fn = pick<PRO_PREQ, EPI_STORE>((int)group_size, gs.RU, gs.JU, gs.FIN, gs.PF);
     if (!fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel for tile %dx%d", gs.RU, gs.JU);
     const size_t smem = gemv_smem_bytes((int)n, (int)group_size, gs.RU, false);
     if ((rc = set_max_smem((const void*)fn, smem))) return rc;

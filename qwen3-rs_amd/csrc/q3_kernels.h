@@ -752,7 +752,10 @@ __device__ __forceinline__ float ordered_row_sum(const float* t, int ng) {
 // all-reduce every lane of a group holds the group's term; the row's sum is folded in ascending group order by a chain
 // of 16 DPP adds per 1 KiB chunk (the running sum hops from group to group, lane 4g+3 -> 4g+7), all rows of the tile in
 // flight together; the chunk total is read from lane 63 and carries into the next chunk / tile.
-template <int PRO, int EPI, int LPG_T, int RU, int JU, int FIN = 0>
+// PF = 1 (streaming launches where every wave has at least two tiles): the SECOND tile is requested before the activation
+// prologue as well, so 2 x 8 KiB per wave (32 MB chip-wide at 2 workgroups per CU) are in flight while the norm / exact
+// sum / quantize run -- the prologue no longer opens a bubble in the HBM stream.
+template <int PRO, int EPI, int LPG_T, int RU, int JU, int FIN = 0, int PF = 0>
 __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     stamp(a, 0);
@@ -959,6 +962,13 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
     __builtin_amdgcn_sched_barrier(0);        // (pin the issue order: vmcnt retires in order)
     RA = batch_rows(min(cb, nb - 1));         // (idle waves re-read a valid batch; nothing is stored)
     load_tile(TA, RA, 0);                     // ... then the first weight tile ...
+    int pb = cb, pjt = 1;                     // PF: coordinates of the tile preloaded into TB
+    if constexpr (PF != 0) {
+        if (pjt == njt) { pjt = 0; pb = cb + nwaves; }
+        // unconditional (static load count for the prologue's vmcnt): a wave without a second tile re-reads a valid one
+        if (pjt == 0) RB = batch_rows(min(pb, nb - 1)); else RB = RA;
+        load_tile(TB, RB, pjt);
+    }
     __builtin_amdgcn_sched_barrier(0);
     stamp(a, 1);
     if (Q3_DEV_ABLATE(a, 1)) {
@@ -971,21 +981,32 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
     }
     stamp(a, 2);
     if (any && !Q3_DEV_ABLATE(a, 2)) {
-        for (;;) {
-            int nb_ = cb, njt_ = cjt + 1;
-            if (njt_ == njt) { njt_ = 0; nb_ = cb + nwaves; }
-            if (nb_ >= nb) {
-                compute_tile(TA, RA, cjt);
-                stamp(a, 3);
-                if (cjt == njt - 1) finish(RA);
-                stamp(a, 4);
-                break;
-            }
-            if (njt_ == 0) RB = batch_rows(nb_); else RB = RA;
-            load_tile(TB, RB, njt_);
-            compute_tile(TA, RA, cjt);
+        bool enter_mid = false;               // PF: the loop is entered at its midpoint (current tile in TB)
+        if constexpr (PF != 0) {
+            compute_tile(TA, RA, cjt);        // TB's loads are younger: counted wait
             if (cjt == njt - 1) finish(RA);
-            cb = nb_; cjt = njt_;
+            enter_mid = pb < nb;
+            cb = pb; cjt = pjt;
+        }
+        if (PF == 0 || enter_mid) for (;;) {
+            int nb_, njt_;
+            if (!(PF != 0 && enter_mid)) {
+                nb_ = cb; njt_ = cjt + 1;
+                if (njt_ == njt) { njt_ = 0; nb_ = cb + nwaves; }
+                if (nb_ >= nb) {
+                    compute_tile(TA, RA, cjt);
+                    stamp(a, 3);
+                    if (cjt == njt - 1) finish(RA);
+                    stamp(a, 4);
+                    break;
+                }
+                if (njt_ == 0) RB = batch_rows(nb_); else RB = RA;
+                load_tile(TB, RB, njt_);
+                compute_tile(TA, RA, cjt);
+                if (cjt == njt - 1) finish(RA);
+                cb = nb_; cjt = njt_;
+            }
+            enter_mid = false;
 
             nb_ = cb; njt_ = cjt + 1;
             if (njt_ == njt) { njt_ = 0; nb_ = cb + nwaves; }
@@ -1580,13 +1601,15 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
             const v4f* pp = (const v4f*)att_p + 8 * c;
 #pragma unroll
             for (int u4 = 0; u4 < 8; ++u4) {
-                // probabilities of timesteps 32c+4u4 .. +3; past the context p = +0.0 and R holds the (finite) row pos
-                // again, so the term is +-0.0 and o + (+-0.0) == o (o starts from +0.0 and is never -0.0)
-                const v4f pv = pp[u4];
-                float pr = pv.x * R[4 * u4 + 0]; o = o + pr;
-                pr = pv.y * R[4 * u4 + 1]; o = o + pr;
-                pr = pv.z * R[4 * u4 + 2]; o = o + pr;
-                pr = pv.w * R[4 * u4 + 3]; o = o + pr;
+                if (32 * c + 4 * u4 < np) {               // wave-uniform: the chain stops at the context's last float4
+                    // past the context (inside the last float4) p = +0.0 and R holds the finite row pos again: the term
+                    // is +-0.0 and o + (+-0.0) == o (o starts from +0.0 and is never -0.0)
+                    const v4f pv = pp[u4];
+                    float pr = pv.x * R[4 * u4 + 0]; o = o + pr;
+                    pr = pv.y * R[4 * u4 + 1]; o = o + pr;
+                    pr = pv.z * R[4 * u4 + 2]; o = o + pr;
+                    pr = pv.w * R[4 * u4 + 3]; o = o + pr;
+                }
             }
         };
         for (int c = 0; 32 * c < np; c += 2) {

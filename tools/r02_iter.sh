@@ -16,3 +16,11 @@ Q3_STAMPS=1 Q3_STRICT=1 Q3_HIP_LIB=qwen3-rs_amd/libqwen3_hip_dev.so Q3_NTOK=32 t
 tail -9 $out/stamps.log
 for w in 2 3; do echo "Q3_WG_PER_CU_SMALL=$w"; Q3_WG_PER_CU_SMALL=$w Q3_STRICT=1 Q3_NTOK=128 timeout 300 python tools/gen_loop.py 2>&1 | tail -1; done
 echo "default, 128 tok"; Q3_STRICT=1 Q3_NTOK=128 timeout 300 python tools/gen_loop.py 2>&1 | tail -1
+timeout 600 python bench.py --shape qwen3-8b --steps 32 --warmup 4 --no-cpu-baseline --no-other-configs > $out/bench8b.json 2> $out/bench8b.err; echo "bench8b rc=$?"
+python3 - <<PY
+import json
+try:
+    d=json.load(open("$out/bench8b.json"))
+    print("8B tok/s", d["value"], "frac", d["roofline"]["frac"], [(k["kernel"],k["avg_us"],k.get("achieved_GBps")) for k in d["roofline"]["per_kernel"]])
+except Exception as e: print("bench8b parse failed", e)
+PY
