@@ -206,26 +206,27 @@ struct Seg {
 };
 
 struct GemvArgs {
-    Seg seg[3];
-    long long qkv_dw[2], qkv_ds[2], qkv_do[2];  // EPI_QKV: byte deltas seg1-seg0, seg2-seg1 (wq, ws, out)
+    // hot first: what the issue phase needs sits in the first 64 bytes of the kernarg segment (one scalar load)
+    const float* in;       // PRO_QUANT: f32[n]; PRO_NORM: x f32[n]
+    const float* norm_w;   // PRO_NORM*: RMSNorm weight f32[n]
+    State* st;             // token / pos
     int n;               // contraction length (bytes per weight row)
     int group;           // quantization group size G
-    int vr;              // rows per wave batch == the kernel's RU template parameter (host bookkeeping)
     int total_rows;      // sum of seg rows (EPI_SWIGLU: hidden units * 2 handled via seg[0],seg[1])
     int strict;
+    Seg seg[3];
+    long long qkv_dw[2], qkv_ds[2], qkv_do[2];  // EPI_QKV: byte deltas seg1-seg0, seg2-seg1 (wq, ws, out)
+    int vr;              // rows per wave batch == the kernel's RU template parameter (host bookkeeping)
     int debug;           // developer ablation bits (Q3_ABLATE): 1 skip prologue math, 2 skip tiles, 4 skip ordered sum
     unsigned long long* stamps;  // developer timeline: 8 s_memtime stamps written by (block stamp_block, wave 0)
     int stamp_block;
-    // prologue inputs
-    const float* in;       // PRO_QUANT: f32[n]; PRO_NORM: x f32[n]
-    const float* norm_w;   // PRO_NORM*: RMSNorm weight f32[n]
+    // other prologue inputs
     const int8_t* pre_q;   // PRO_PREQ: already-quantized activation
     const float* pre_s;
     const int8_t* emb_q;   // PRO_EMBED_NORM: embedding table
     const float* emb_s;
     float* x_out;          // PRO_EMBED_NORM: residual stream x (written by workgroup 0)
     float* tap_out;        // PRO_NORM: optional copy of the normalised vector (workgroup 0)
-    State* st;             // token / pos
     unsigned long long* argmax_slots;  // EPI_LOGITS: one (key<<32|index) per workgroup
     int seq_len;
 };
@@ -865,6 +866,7 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
                 const int c = lane + 64 * (jt * JU + j);
                 const v4i xv = ((const v4i*)sm.xq)[c];
                 const float xsc = sm.xs[c >> 2];
+                float t[RU], acc[RU];
 #pragma unroll
                 for (int r = 0; r < RU; ++r) {
                     int d = __builtin_amdgcn_sdot4(T.w[r][j].x, xv.x, 0, false);
@@ -872,18 +874,23 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
                     d = __builtin_amdgcn_sdot4(T.w[r][j].z, xv.z, d, false);
                     d = __builtin_amdgcn_sdot4(T.w[r][j].w, xv.w, d, false);
                     d = group_sum_i32_t<4>(d);
-                    float t = (float)d * T.sc[r][j];   // tensor.rs:59  ((dot as f32) * ws) * xs -- identical in the 4 lanes of a group
-                    t = t * xsc;
-                    // ascending-group fold as a chain of DPP adds: group g's running sum lives in lane 4g+3 and moves to
-                    // lane 4g+7 by row_shr:4 (row_bcast:15 across the 16-lane rows); lane 63 ends with the chunk's sum
-                    float acc = racc[r] + t;
-#pragma unroll
-                    for (int g = 1; g < 16; ++g) {
-                        const float prev = (g & 3) ? dpp_f<0x114>(acc) : dpp_f<0x142>(acc);
-                        acc = prev + t;
-                    }
-                    racc[r] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 63));
+                    t[r] = (float)d * T.sc[r][j];   // tensor.rs:59  ((dot as f32) * ws) * xs -- identical in the 4 lanes of a group
+                    t[r] = t[r] * xsc;
+                    acc[r] = racc[r] + t[r];
                 }
+                // ascending-group fold as a chain of DPP adds: group g's running sum lives in lane 4g+3 and moves to lane
+                // 4g+7 by row_shr:4 (row_bcast:15 across the 16-lane rows); lane 63 ends with the chunk's sum.  A hop
+                // costs 17 cycles; the rows' chains are independent, so they are issued interleaved (step-major).
+#pragma unroll
+                for (int g = 1; g < 16; ++g) {
+#pragma unroll
+                    for (int r = 0; r < RU; ++r) {
+                        const float prev = (g & 3) ? dpp_f<0x114>(acc[r]) : dpp_f<0x142>(acc[r]);
+                        acc[r] = prev + t[r];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < RU; ++r) racc[r] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc[r]), 63));
             }
             return;
         }
@@ -1599,12 +1606,15 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
         float o = 0.0f;
         auto fold_chunk = [&](const float (&R)[32], int c) {
             const v4f* pp = (const v4f*)att_p + 8 * c;
+            v4f pq[8];
+#pragma unroll
+            for (int u4 = 0; u4 < 8; ++u4) pq[u4] = pp[u4];   // one burst of LDS reads, not one round trip per step
 #pragma unroll
             for (int u4 = 0; u4 < 8; ++u4) {
                 if (32 * c + 4 * u4 < np) {               // wave-uniform: the chain stops at the context's last float4
                     // past the context (inside the last float4) p = +0.0 and R holds the finite row pos again: the term
                     // is +-0.0 and o + (+-0.0) == o (o starts from +0.0 and is never -0.0)
-                    const v4f pv = pp[u4];
+                    const v4f pv = pq[u4];
                     float pr = pv.x * R[4 * u4 + 0]; o = o + pr;
                     pr = pv.y * R[4 * u4 + 1]; o = o + pr;
                     pr = pv.z * R[4 * u4 + 2]; o = o + pr;
