@@ -472,6 +472,119 @@ def test_batched_prefill_is_sequential_equivalent(q3, shape_name, n_prompt, firs
             t.prefill([1, 2, 10 ** 7], 0, batched=True)
 
 
+def test_batched_prefill_kv_and_token_vs_oracle(q3, oracle, tmp_path_factory):
+    """The batched (int8 MFMA, 32 positions per weight pass) prefill against the ORACLE directly, not only against the
+    sequential HIP path: every K/V row of a 70-token chat-mode prompt (generation.rs:116-123) and the first generated
+    token, bit for bit."""
+    ck = q3.checkpoint
+    shape = ck.SHAPES["small-hd128"]
+    path = str(tmp_path_factory.mktemp("preo") / "small-hd128.bin")
+    ck.write_synthetic_checkpoint(path, shape, seed=31)
+    prompt = ck.iter_prompt_tokens(shape, 8, 70)
+    om = oracle.OracleModel(path, 128)
+    for p, tok in enumerate(prompt):
+        lg = om.forward(tok, p)
+    ok, ov = om.kv_cache()
+    kvd = shape.n_kv_heads * shape.head_dim
+    with q3.TransformerBuilder(path).with_ctx_length(128).build() as t:
+        assert t.prefill(prompt, 0, batched=True) == oracle.sample_argmax(lg)
+        for layer in range(shape.n_layers):
+            assert_biteq(t.read_state("key", layer * 128 * kvd, 70 * kvd), ok[layer].reshape(-1)[:70 * kvd], f"key rows layer {layer}")
+            assert_biteq(t.read_state("value", layer * 128 * kvd, 70 * kvd), ov[layer].reshape(-1)[:70 * kvd], f"value rows layer {layer}")
+
+
+def test_batched_decode_8b_layer_dims_vs_forward_and_oracle(q3, oracle):
+    """BASELINE config 4's matrix shapes on the batched path: row lengths 4096 / 12288 (64 and 192 groups per row), 32
+    heads over 8 kv heads, untied classifier -- 2 layers, reduced vocabulary.  32 streams x 8 steps: every stream's
+    logits bit-identical to q3_forward on the same (token, pos) sequence for the first 4 streams, and 2 streams
+    against the oracle."""
+    ck = q3.checkpoint
+    name = "qwen3-8b-dims-l2"
+    shape = ck.SHAPES[name]
+    path = os.path.join(os.environ.get("Q3_CKPT_DIR", "/tmp"), f"q3_{name}.bin")
+    ck.ensure_synthetic_checkpoint(path, shape, seed=1235)
+    n_streams, steps = 32, 8
+    rng = np.random.default_rng(5)
+    toks0 = [int(t) for t in rng.integers(0, shape.vocab_size, n_streams)]
+    pos0 = [int(p) for p in rng.integers(0, 9, n_streams)]
+    with q3.TransformerBuilder(path).with_ctx_length(64).build() as t:
+        ref = []
+        for i in range(4):
+            t.reset_kv()
+            tok, ll = toks0[i], []
+            for k in range(steps):
+                lg = np.array(t.forward(tok, pos0[i] + k), copy=True)
+                ll.append(lg)
+                tok = q3.sample_argmax(lg)
+            ref.append(ll)
+        t.batch_init(n_streams, 64)
+        toks, all_lg = list(toks0), []
+        for k in range(steps):
+            lg, am = t.forward_batch(toks, [p + k for p in pos0])
+            all_lg.append(np.array(lg, copy=True))
+            for i in range(4):
+                assert_biteq(lg[i], ref[i][k], f"stream {i} step {k}")
+            toks = am
+    om = oracle.OracleModel(path, 64)
+    for i in (7, 31):
+        om.reset()
+        tok = toks0[i]
+        for k in range(steps):
+            lg = om.forward(tok, pos0[i] + k)
+            assert_biteq(all_lg[k][i], lg, f"stream {i} step {k} vs oracle")
+            tok = oracle.sample_argmax(lg)
+
+
+def test_full_size_8b_batch32_streams_equal_single_stream(q3):
+    """BASELINE config 4 at FULL size (Qwen3-8B shape, 36 layers, vocab 151936, untied): 32 concurrent greedy streams x
+    16 steps; two of the streams re-run single-stream on the same engine must give the same tokens (the size-independent
+    property; the oracle needs ~1 s per 8B token, so it checks the first token of one stream only)."""
+    ck = q3.checkpoint
+    shape = ck.SHAPES["qwen3-8b"]
+    path = os.path.join(os.environ.get("Q3_CKPT_DIR", "/tmp"), "qwen3-8b-seed1236.q3bin")    # shared with tools/bench_batch.py
+    ck.ensure_synthetic_checkpoint(path, shape, seed=1236)
+    prompts = [ck.iter_prompt_tokens(shape, 1236 + 1000 + i, 8) for i in range(32)]
+    first_tok, first_pos = [p[-1] for p in prompts], [len(p) - 1 for p in prompts]
+    with q3.TransformerBuilder(path).with_ctx_length(64).build() as t:
+        t.batch_init(32, 64)
+        out = t.generate_greedy_batch(first_tok, first_pos, 16)
+        assert out.shape == (32, 16)
+        for i in (0, 19):
+            t.reset_kv()
+            assert t.generate_greedy(first_tok[i], first_pos[i], 16) == [int(v) for v in out[i]], f"stream {i}"
+        assert len({tuple(int(v) for v in row) for row in out}) > 16      # the streams really are different sequences
+
+
+def test_full_size_4b_batched_prefill_256_tokens(q3, oracle):
+    """BASELINE config 3 at FULL size (Qwen3-4B shape: dim 2560 / hidden 9728 are not multiples of 1 KiB, 36 layers): a
+    256-token batched prefill writes the same K/V rows as the sequential device loop (checked on the first and last
+    layer) and returns the same first token; rows 0..2 and the logits-side argmax chain are checked against the oracle
+    for the first three positions."""
+    ck = q3.checkpoint
+    shape = ck.SHAPES["qwen3-4b"]
+    path = os.path.join(os.environ.get("Q3_CKPT_DIR", "/tmp"), "qwen3-4b-seed1235.q3bin")     # shared with tools/bench_chat.py
+    ck.ensure_synthetic_checkpoint(path, shape, seed=1235)
+    prompt = ck.iter_prompt_tokens(shape, 1235, 256)
+    kvd = shape.n_kv_heads * shape.head_dim
+    L = shape.n_layers
+    with q3.TransformerBuilder(path).with_ctx_length(320).build() as t:
+        first_seq = t.prefill(prompt, 0)
+        want = {l: (t.read_state("key", l * 320 * kvd, 256 * kvd), t.read_state("value", l * 320 * kvd, 256 * kvd)) for l in (0, L - 1)}
+        t.reset_kv()
+        assert t.prefill(prompt, 0, batched=True) == first_seq
+        for l in (0, L - 1):
+            assert_biteq(t.read_state("key", l * 320 * kvd, 256 * kvd), want[l][0], f"key rows layer {l}")
+            assert_biteq(t.read_state("value", l * 320 * kvd, 256 * kvd), want[l][1], f"value rows layer {l}")
+        got3 = {l: (t.read_state("key", l * 320 * kvd, 3 * kvd), t.read_state("value", l * 320 * kvd, 3 * kvd)) for l in (0, L - 1)}
+    om = oracle.OracleModel(path, 320)
+    for p in range(3):
+        om.forward(prompt[p], p)
+    ok, ov = om.kv_cache()
+    for l in (0, L - 1):
+        assert_biteq(got3[l][0], ok[l].reshape(-1)[:3 * kvd], f"oracle key rows layer {l}")
+        assert_biteq(got3[l][1], ov[l].reshape(-1)[:3 * kvd], f"oracle value rows layer {l}")
+
+
 @pytest.mark.parametrize("n_heads,n_kv,hd", [(4, 4, 32), (8, 1, 64), (6, 2, 128)])
 def test_batched_paths_other_head_layouts(q3, n_heads, n_kv, hd, tmp_path_factory):
     """kv_mul 1 (no sharing, head_dim < 64), kv_mul 8 (falls back to the per-head attention kernel; batched prefill then
