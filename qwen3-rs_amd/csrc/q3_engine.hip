@@ -288,7 +288,7 @@ GemvShape plan_gemv(int units, int n, int G, bool swiglu, int row_align, int n_c
     const int ru_max = 8 / g.JU, ru_min = swiglu ? 2 : 1;
     const int waves = n_cu * wg_per_cu * kWaves;
     // rows that are a whole number of tiles fold the group terms in registers (k_gemv FIN = 1)
-    if (allow_fin && env_int("Q3_GEMV_FIN", 1) && G == 64 && nchunks % (64 * g.JU) == 0 &&
+    if (allow_fin && env_int("Q3_GEMV_FIN", 1) && G == 64 && (nchunks % 4) == 0 &&
         launch_bytes < ((size_t)env_int("Q3_GEMV_FIN_MAXMB", 1 << 20) << 20)) g.FIN = 1;
     int best_ru = ru_min;
     long best_cost = -1;

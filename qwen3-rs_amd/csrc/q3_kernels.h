@@ -749,7 +749,7 @@ __device__ __forceinline__ float ordered_row_sum(const float* t, int ng) {
     return acc;
 }
 
-// FIN = 1 (latency-bound launches, G = 64, rows a whole number of tiles): the group terms never touch LDS.  After the DPP
+// FIN = 1 (G = 64): the group terms never touch LDS.  After the DPP
 // all-reduce every lane of a group holds the group's term; the row's sum is folded in ascending group order by a chain
 // of 16 DPP adds per 1 KiB chunk (the running sum hops from group to group, lane 4g+3 -> 4g+7), all rows of the tile in
 // flight together; the chunk total is read from lane 63 and carries into the next chunk / tile.
@@ -863,9 +863,14 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
             }
 #pragma unroll
             for (int j = 0; j < JU; ++j) {
+                // rows that are not a whole number of wave-loads (2560, 9728): lanes past the row end hold a re-read chunk;
+                // their term is forced to +0.0, which leaves every running sum unchanged (a sum is -0.0 only before its first
+                // term, and the padding comes after the row's last group)
                 const int c = lane + 64 * (jt * JU + j);
-                const v4i xv = ((const v4i*)sm.xq)[c];
-                const float xsc = sm.xs[c >> 2];
+                const bool cok = chunks_fit || c < nchunks;
+                const int cc = chunks_fit ? c : min(c, nchunks - 1);
+                const v4i xv = ((const v4i*)sm.xq)[cc];
+                const float xsc = sm.xs[cc >> 2];
                 float t[RU], acc[RU];
 #pragma unroll
                 for (int r = 0; r < RU; ++r) {
@@ -876,6 +881,7 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
                     d = group_sum_i32_t<4>(d);
                     t[r] = (float)d * T.sc[r][j];   // tensor.rs:59  ((dot as f32) * ws) * xs -- identical in the 4 lanes of a group
                     t[r] = t[r] * xsc;
+                    t[r] = cok ? t[r] : 0.0f;
                     acc[r] = racc[r] + t[r];
                 }
                 // ascending-group fold as a chain of DPP adds: group g's running sum lives in lane 4g+3 and moves to lane
@@ -1658,7 +1664,7 @@ __host__ __device__ inline size_t attn_scores_smem_bytes(int hd) {
 }
 __host__ __device__ inline size_t attn_out_smem_bytes(int hd, int seq_len, int w) {
     const int pl = ((seq_len + 255) & ~255) <= kPLds ? ((seq_len + 255) & ~255) : 0;
-    return 4 * ((size_t)(kVChunk + kVPad) * w + kVChunk + 64 + (size_t)kWaves * w + (size_t)pl);
+    return 4 * (2 * (size_t)(kVChunk + kVPad) * w + 2 * kVChunk + 64 + (size_t)kWaves * w + (size_t)pl);   // V / p chunk tiles double buffered
 }
 
 __global__ __launch_bounds__(kWG) void k_attn_scores(const AttnArgs a) {
@@ -1765,9 +1771,9 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int hd = a.hd;
     const int w = a.slice_w;                             // slice width (power of two >= 8, or hd)
-    float* vbuf = (float*)smem_raw;                      // [kVChunk][w]  (reference order: [w][kVChunk + kVPad])
-    float* pbuf = vbuf + (kVChunk + kVPad) * w;          // [kVChunk]
-    float* red = pbuf + kVChunk;                         // [64]
+    float* vbuf0 = (float*)smem_raw;                     // 2 x [kVChunk][w]  (reference order: [w][kVChunk + kVPad])
+    float* pbuf0 = vbuf0 + 2 * (kVChunk + kVPad) * w;    // 2 x [kVChunk]
+    float* red = pbuf0 + 2 * kVChunk;                    // [64]
     float* opart = red + 64;                             // [kWaves][w]
     float* p_lds = opart + kWaves * w;                   // [npad] when the row fits (see attn_out_smem_bytes)
 
@@ -1825,7 +1831,9 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
         }
     };
     constexpr int VLD = kVChunk + kVPad;
-    auto v_commit = [&](const VRegs& R, int c0) {
+    auto v_commit = [&](const VRegs& R, int c0, int buf) {
+        float* vbuf = vbuf0 + buf * (kVChunk + kVPad) * w;
+        float* pbuf = pbuf0 + buf * kVChunk;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int r = r0 + u * rps;
@@ -1847,12 +1855,11 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
         }
         for (int t = tid; t < kVChunk; t += kWG) pbuf[t] = (c0 + t < np) ? p[c0 + t] : 0.0f;
     };
-    auto chunk = [&](VRegs& R, int c0) {
+    // fold chunk c0 out of LDS tile `buf` (committed one barrier earlier)
+    auto fold = [&](int c0, int buf) {
         const int cnt = min(kVChunk, np - c0);
-        __syncthreads();                                 // previous chunk fully consumed
-        v_commit(R, c0);
-        __syncthreads();
-        if (c0 + 2 * kVChunk < np) v_issue(R, c0 + 2 * kVChunk);   // this register set is free again: two chunks ahead
+        const float* vbuf = vbuf0 + buf * (kVChunk + kVPad) * w;
+        const float* pbuf = pbuf0 + buf * kVChunk;
         if (a.strict) {
             if (tid < w) {
                 // one sequential chain per output element (layers.rs:406-417); operands arrive as float4 (4 timesteps)
@@ -1896,11 +1903,29 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
             }
         }
     };
+    // Two LDS tiles, one barrier per chunk: while the chain lanes fold chunk c out of one tile, every thread first commits
+    // chunk c+1 (already in registers) into the other and requests chunk c+3 into the freed registers -- the staging no longer
+    // sits between two barriers in front of every fold.
+    constexpr int K = kVChunk;
     v_issue(vra, 0);
-    if (kVChunk < np) v_issue(vrb, kVChunk);
-    for (int c0 = 0; c0 < np; c0 += 2 * kVChunk) {
-        chunk(vra, c0);
-        if (c0 + kVChunk < np) chunk(vrb, c0 + kVChunk);
+    if (K < np) v_issue(vrb, K);
+    v_commit(vra, 0, 0);
+    if (2 * K < np) v_issue(vra, 2 * K);
+    __syncthreads();
+    for (int c0 = 0; c0 < np; c0 += 2 * K) {
+        if (c0 + K < np) {
+            v_commit(vrb, c0 + K, 1);
+            if (c0 + 3 * K < np) v_issue(vrb, c0 + 3 * K);
+        }
+        fold(c0, 0);
+        __syncthreads();
+        if (c0 + K >= np) break;
+        if (c0 + 2 * K < np) {
+            v_commit(vra, c0 + 2 * K, 0);
+            if (c0 + 4 * K < np) v_issue(vra, c0 + 4 * K);
+        }
+        fold(c0 + K, 1);
+        __syncthreads();
     }
     float* out = a.xb + (size_t)h * hd + (size_t)sl * w;
     if (a.strict) {

@@ -305,7 +305,9 @@ class TransformerBuilder:
         self.checkpoint_path = checkpoint_path
         self.ctx_length: Optional[int] = None
         self.device = int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("Q3_DEVICE_FROM_RANK") else 0
-        self.flags = 0
+        # Q3_EAGER=1: launch kernels eagerly instead of replaying hipGraphs (profiling runs: rocprofv3's kernel trace
+        # of this ROCm build crashes on long back-to-back graph replays)
+        self.flags = FLAG_NO_GRAPH if os.environ.get("Q3_EAGER_LAUNCH") else 0
 
     def with_ctx_length(self, ctx_length: Optional[int]) -> "TransformerBuilder":
         self.ctx_length = ctx_length
