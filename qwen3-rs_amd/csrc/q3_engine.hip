@@ -680,6 +680,7 @@ int q3_engine::build_plan() {
         if (!L0.is_attn) { plan_long.push_back(L0); continue; }
         Launch A = L0, B = L0;
         A.attn_kind = 1;
+        A.aa.stamps = nullptr;            // developer timeline of the long plan: k_attn_out's
         A.aa.att_global = d_att;
         A.aa.att_stride = att_stride;
         A.aa.q_out = nullptr;

@@ -1182,7 +1182,7 @@ __device__ __forceinline__ void stage_commit(const StageRegs& sr, float* lds, in
 }
 
 #ifdef Q3_DEV
-#define ATT_STAMP(i) do { if (a.stamps != nullptr && blockIdx.x == 3 && threadIdx.x == 0) a.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ATT_STAMP(i) do { if (a.stamps != nullptr && blockIdx.x == 3 && blockIdx.y == 0 && threadIdx.x == 0) a.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define ATT_STAMP(i) do { } while (0)
 #endif
@@ -1664,7 +1664,7 @@ __host__ __device__ inline size_t attn_scores_smem_bytes(int hd) {
 }
 __host__ __device__ inline size_t attn_out_smem_bytes(int hd, int seq_len, int w) {
     const int pl = ((seq_len + 255) & ~255) <= kPLds ? ((seq_len + 255) & ~255) : 0;
-    return 4 * (2 * (size_t)(kVChunk + kVPad) * w + 2 * kVChunk + 64 + (size_t)kWaves * w + (size_t)pl);   // V / p chunk tiles double buffered
+    return 4 * (2 * (size_t)(kVChunk + kVPad) * w + 2 * kVChunk + 64 + (size_t)kWaves * w + (size_t)pl) + 32 * 8;   // V / p chunk tiles double buffered; exp2 table
 }
 
 __global__ __launch_bounds__(kWG) void k_attn_scores(const AttnArgs a) {
@@ -1769,6 +1769,7 @@ __global__ __launch_bounds__(kWG) void k_attn_scores(const AttnArgs a) {
 
 __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    ATT_STAMP(0);
     const int hd = a.hd;
     const int w = a.slice_w;                             // slice width (power of two >= 8, or hd)
     float* vbuf0 = (float*)smem_raw;                     // 2 x [kVChunk][w]  (reference order: [w][kVChunk + kVPad])
@@ -1785,30 +1786,11 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
     const int np = pos + 1;
     const int npad = (np + 255) & ~255;                  // whole 64 x (npad/64) blocks for the exact sum
     const float* src = a.att_global + (size_t)h * a.att_stride;
-    const bool p_in_lds = ((a.seq_len + 255) & ~255) <= kPLds;
+    const int npad_max = (a.seq_len + 255) & ~255;
+    const bool p_in_lds = npad_max <= kPLds;
     float* p = p_in_lds ? p_lds : a.att_priv + ((size_t)h * nsl + sl) * a.att_stride;
     const float* vbase = a.value_cache + (size_t)kvh * hd + (size_t)sl * w;
 
-    // ---- softmax (layers.rs:495-506) into this workgroup's private probability row
-    float m = -__builtin_inff();
-    for (int t = tid; t < np; t += kWG) m = fmaxf(m, src[t]);
-    m = block_max(m, red);
-    float part = 0.0f;
-    for (int t = tid; t < npad; t += kWG) {
-        float e = 0.0f;                                  // +0.0 padding leaves every partial sum unchanged
-        if (t < np) { e = q3_expf(src[t] - m); part = part + e; }
-        p[t] = e;
-    }
-    __syncthreads();
-    float sum;
-    if (a.strict) sum = seq_sum_blocks(p, 64, npad >> 6, npad >> 6, nullptr);
-    else sum = block_sum_fast(part, red);
-    const float inv = 1.0f / sum;
-    __syncthreads();
-    for (int t = tid; t < np; t += kWG) p[t] = p[t] * inv;
-    __syncthreads();
-
-    // ---- out[e] = sum_t p[t] * V[t][e]  (layers.rs:406-417), V slices staged kVChunk timesteps at a time
     const int w4s = __builtin_ctz(w >> 2);               // float4 per slice row = 1 << w4s
     const int rps = kWG >> w4s;                          // rows per staging pass of the whole workgroup
     const int npass = (kVChunk + rps - 1) / rps;         // <= 8 (w = 32) ... 2 (w = 8)
@@ -1830,6 +1812,60 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
             }
         }
     };
+    constexpr int K = kVChunk;
+    v_issue(vra, 0);                                     // the first two V chunks travel under the softmax
+    if (K < np) v_issue(vrb, K);
+
+    // exp2 table of q3_expf staged in LDS (a dependent global load per exp otherwise)
+    unsigned long long* etab = (unsigned long long*)(p_lds + (p_in_lds ? npad_max : 0));
+    if (tid < 32) etab[tid] = kExp2Tab[tid];
+
+    // ---- softmax (layers.rs:495-506) into this workgroup's private probability row.  Scores are pulled 8 per thread at
+    // a time (independent loads in flight together), twice: the second pass hits L1.
+    float m = -__builtin_inff();
+    for (int t0 = 0; t0 < np; t0 += 8 * kWG) {
+        float sv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sv[u] = src[min(t0 + u * kWG + tid, np - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m = fmaxf(m, sv[u]);
+    }
+    m = block_max(m, red);                               // (its barriers also publish etab)
+    ATT_STAMP(1);
+    float part = 0.0f;
+    for (int t0 = 0; t0 < npad; t0 += 8 * kWG) {
+        float sv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sv[u] = src[min(t0 + u * kWG + tid, np - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = t0 + u * kWG + tid;
+            if (t < npad) {
+                float e = q3_expf_t(t < np ? sv[u] - m : 0.0f, etab);
+                e = t < np ? e : 0.0f;                   // +0.0 padding leaves every partial sum unchanged
+                part = part + e;
+                p[t] = e;
+            }
+        }
+    }
+    __syncthreads();
+    ATT_STAMP(2);
+    float sum;
+    if (a.strict) {
+        // blocks of 4..64 terms (a power of two: straight-line register folds), one lane each; longer rows take 64 blocks
+        int bl = 4;
+        while (64 * bl < np) bl <<= 1;
+        if (bl <= 64) sum = seq_sum_blocks(p, (np + bl - 1) / bl, bl, bl, nullptr);
+        else sum = seq_sum_blocks(p, 64, npad >> 6, npad >> 6, nullptr);
+    } else sum = block_sum_fast(part, red);
+    ATT_STAMP(3);
+    const float inv = 1.0f / sum;
+    __syncthreads();
+    for (int t = tid; t < np; t += kWG) p[t] = p[t] * inv;
+    __syncthreads();
+    ATT_STAMP(4);
+
+    // ---- out[e] = sum_t p[t] * V[t][e]  (layers.rs:406-417), V slices staged kVChunk timesteps at a time
     constexpr int VLD = kVChunk + kVPad;
     auto v_commit = [&](const VRegs& R, int c0, int buf) {
         float* vbuf = vbuf0 + buf * (kVChunk + kVPad) * w;
@@ -1906,9 +1942,6 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
     // Two LDS tiles, one barrier per chunk: while the chain lanes fold chunk c out of one tile, every thread first commits
     // chunk c+1 (already in registers) into the other and requests chunk c+3 into the freed registers -- the staging no longer
     // sits between two barriers in front of every fold.
-    constexpr int K = kVChunk;
-    v_issue(vra, 0);
-    if (K < np) v_issue(vrb, K);
     v_commit(vra, 0, 0);
     if (2 * K < np) v_issue(vra, 2 * K);
     __syncthreads();
@@ -1918,6 +1951,7 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
             if (c0 + 3 * K < np) v_issue(vrb, c0 + 3 * K);
         }
         fold(c0, 0);
+        if (c0 == 0) ATT_STAMP(5);
         __syncthreads();
         if (c0 + K >= np) break;
         if (c0 + 2 * K < np) {
@@ -1927,6 +1961,7 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
         fold(c0 + K, 1);
         __syncthreads();
     }
+    ATT_STAMP(6);
     float* out = a.xb + (size_t)h * hd + (size_t)sl * w;
     if (a.strict) {
         if (tid < w) out[tid] = o_s;
