@@ -184,6 +184,12 @@ def worker_main(args):
     shape, first_tok, first_pos = run_setup(args)
     K, W = args.steps, args.warmup
     path = ckpt_path(args)
+    if not args.worker and not args.stub_engine:
+        # launched by torchrun (no parent of ours wrote the checkpoint): rank 0 writes it, everyone waits
+        if rank == 0:
+            from qwen3_rs_amd import checkpoint as ck
+            ck.ensure_synthetic_checkpoint(path, shape, seed=SEED)
+        barrier()
     if args.stub_engine:
         eng = _StubEngine(rank)
     else:

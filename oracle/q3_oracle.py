@@ -10,7 +10,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libq3_oracle.so")
+# Q3_ORACLE_LIB selects another build of the same source (the ASan/UBSan one: `make -C oracle libq3_oracle_asan.so`,
+# run with LD_PRELOAD=$(gcc -print-file-name=libasan.so) -- see tests/README note in DESIGN.md section 7)
+_LIB_PATH = os.environ.get("Q3_ORACLE_LIB") or os.path.join(_HERE, "libq3_oracle.so")
 
 
 class Config(C.Structure):
@@ -21,6 +23,8 @@ class Config(C.Structure):
 
 def build(force: bool = False) -> str:
     src = [os.path.join(_HERE, f) for f in ("q3_oracle.c", "q3_oracle.h", "Makefile")]
+    if os.environ.get("Q3_ORACLE_LIB"):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src):
         subprocess.check_call(["make", "-s", "-C", _HERE, "libq3_oracle.so"])

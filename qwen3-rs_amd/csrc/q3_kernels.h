@@ -137,20 +137,19 @@ __device__ __constant__ unsigned long long kExp2Tab[32] = {
 // `tab`: the 32-entry exp2 table -- kExp2Tab in constant memory (a dependent global load in the middle of the
 // evaluation), or a copy the kernel staged in LDS (latency-critical single-wave phases).
 __device__ __forceinline__ float q3_expf_t(float x, const unsigned long long* tab) {
+    // Branch-free: the main path is evaluated for every input and the special cases (|x| >= 88: overflow, underflow,
+    // infinities, NaN) are patched in with selects afterwards, so several independent exps interleave in one wave
+    // instead of serialising behind a divergent range check (an exp is ~12 dependent f64 operations).
     const unsigned ux = __float_as_uint(x);
     const unsigned abstop = (ux >> 20) & 0x7ffu;
-    if (abstop >= 0x42bu) {  // |x| >= 88.0f
-        if (ux == 0xff800000u) return 0.0f;
-        if (abstop >= 0x7f8u) return x + x;
-        if (x > 0x1.62e42ep6f) return __builtin_inff();
-        if (x < -0x1.9fe368p6f) return 0.0f;
-    }
     constexpr double kInvLn2N = 0x1.71547652b82fep+0 * 32.0;
     constexpr double kShift = 0x1.8p+52;
     constexpr double kC0 = 0x1.c6af84b912394p-5 / 32.0 / 32.0 / 32.0;
     constexpr double kC1 = 0x1.ebfce50fac4f3p-3 / 32.0 / 32.0;
     constexpr double kC2 = 0x1.62e42ff0c52d6p-1 / 32.0;
-    const double xd = (double)x;
+    const bool special = abstop >= 0x42bu;                 // |x| >= 88.0f (or not finite)
+    const double xd = (double)x;                           // out-of-range inputs run through too (bit casts only, table
+                                                           // index masked): their result is discarded below
     double z = kInvLn2N * xd;
     double kd = z + kShift;
     const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
@@ -163,7 +162,14 @@ __device__ __forceinline__ float q3_expf_t(float x, const unsigned long long* ta
     double y = kC2 * r + 1.0;
     y = z * r2 + y;
     y = y * s;
-    return (float)y;
+    float res = (float)y;
+    // glibc's special cases, in its order of precedence (e_expf.c)
+    float sp = 0.0f;                                       // x < -0x1.9fe368p6f: underflow to +0 (also -inf)
+    sp = (x > 0x1.62e42ep6f) ? __builtin_inff() : sp;      // overflow
+    sp = (special && !(x > 0x1.62e42ep6f) && !(x < -0x1.9fe368p6f)) ? res : sp;   // 88 <= |x| inside the finite range
+    sp = (abstop >= 0x7f8u) ? (x + x) : sp;                // +inf / NaN
+    sp = (ux == 0xff800000u) ? 0.0f : sp;                  // -inf
+    return special ? sp : res;
 }
 __device__ __forceinline__ float q3_expf(float x) { return q3_expf_t(x, kExp2Tab); }
 
@@ -1855,8 +1861,9 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
         // blocks of 4..64 terms (a power of two: straight-line register folds), one lane each; longer rows take 64 blocks
         int bl = 4;
         while (64 * bl < np) bl <<= 1;
-        if (bl <= 64) sum = seq_sum_blocks(p, (np + bl - 1) / bl, bl, bl, nullptr);
-        else sum = seq_sum_blocks(p, 64, npad >> 6, npad >> 6, nullptr);
+        if (bl <= 32) sum = seq_sum_blocks(p, (np + bl - 1) / bl, bl, bl, nullptr);    // np <= 2048
+        else sum = seq_sum_blocks(p, 64, npad >> 6, npad >> 6, nullptr);              // (64-term blocks at stride 64 floats would
+                                                                                      // read LDS 16-way bank conflicted)
     } else sum = block_sum_fast(part, red);
     ATT_STAMP(3);
     const float inv = 1.0f / sum;

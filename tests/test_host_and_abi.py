@@ -206,3 +206,20 @@ def test_batch_entry_points_reject_prefill_only_context(q3):
     (null engine here: no GPU in the CPU suite; the has_kv guard itself is exercised on the GPU box)."""
     L = q3.load_library()
     assert L.q3_batch_reset_kv(None) == -3
+
+
+def test_bench_under_torchrun_two_ranks_stub_engine():
+    """The driver's N > 1 launch form: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` -- every
+    rank is a worker (RANK / LOCAL_RANK / WORLD_SIZE from the environment), gloo carries the barrier and the aggregate,
+    rank 0 prints the ONE line."""
+    import json
+    import subprocess
+    port = 29700 + (os.getpid() % 200)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6",
+                        "--warmup", "1", "--stub-engine"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and "_tokens" not in d
