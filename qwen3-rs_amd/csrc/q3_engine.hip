@@ -494,7 +494,7 @@ int q3_engine::build_plan() {
     const int G = cfg.group_size, ahd = cfg.n_heads * hd, kvd = cfg.n_kv_heads * hd, S = cfg.seq_len;
     const int strict = (flags & Q3_FLAG_FAST) ? 0 : 1;
     const int small_cap = env_int("Q3_WG_PER_CU_SMALL", 2);   // two workgroups per CU: half the rows (and fold chains) per wave
-    const int big_cap = env_int("Q3_WG_PER_CU_LMHEAD", 4);
+    const int big_cap = env_int("Q3_WG_PER_CU_LMHEAD", 2);   // all workgroups resident at once (the NORM prologue keeps ~190 VGPRs live)
     const int att_lds_max = env_int("Q3_ATT_LDS_MAX", 4096);
 
     split_pos = env_int("Q3_ATT_SPLIT_POS", 256);

@@ -31,6 +31,11 @@
 
 namespace q3 {
 
+// Force a kernel argument into SGPRs at this point: hipcc otherwise issues the scalar loads of a large by-value argument
+// struct in several batches, each next to its first use, and every batch costs a full scalar-memory round trip on the
+// critical path of these latency-bound kernels.  One batch at the very top, one wait.
+#define Q3_PIN_S(x) asm volatile("" ::"s"(x))
+
 constexpr int kWG = 256;       // threads per workgroup
 constexpr int kWaves = 4;      // wavefronts (64 lanes) per workgroup
 constexpr int kMaxVR = 8;      // weight rows a wave finishes per batch
@@ -766,6 +771,26 @@ template <int PRO, int EPI, int LPG_T, int RU, int JU, int FIN = 0, int PF = 0>
 __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     stamp(a, 0);
+    Q3_PIN_S(a.in); Q3_PIN_S(a.n); Q3_PIN_S(a.group); Q3_PIN_S(a.total_rows); Q3_PIN_S(a.strict);
+    Q3_PIN_S(a.seg[0].wq); Q3_PIN_S(a.seg[0].ws); Q3_PIN_S(a.seg[0].out); Q3_PIN_S(a.seg[0].rows);
+    if constexpr (PRO == PRO_NORM || PRO == PRO_EMBED_NORM) Q3_PIN_S(a.norm_w);
+    if constexpr (PRO == PRO_EMBED_NORM) { Q3_PIN_S(a.emb_q); Q3_PIN_S(a.emb_s); Q3_PIN_S(a.x_out); }
+    if constexpr (PRO == PRO_EMBED_NORM || EPI == EPI_QKV) Q3_PIN_S(a.st);
+    if constexpr (PRO == PRO_PREQ) { Q3_PIN_S(a.pre_q); Q3_PIN_S(a.pre_s); }
+    if constexpr (EPI == EPI_SWIGLU) { Q3_PIN_S(a.seg[1].wq); Q3_PIN_S(a.seg[1].ws); }
+    if constexpr (EPI == EPI_QKV) {
+        Q3_PIN_S(a.seg[0].out_pos_stride); Q3_PIN_S(a.seg[1].rows); Q3_PIN_S(a.seg[2].rows);
+        Q3_PIN_S(a.seg[1].out_pos_stride); Q3_PIN_S(a.seg[2].out_pos_stride);
+        Q3_PIN_S(a.qkv_dw[0]); Q3_PIN_S(a.qkv_dw[1]); Q3_PIN_S(a.qkv_ds[0]); Q3_PIN_S(a.qkv_ds[1]);
+        Q3_PIN_S(a.qkv_do[0]); Q3_PIN_S(a.qkv_do[1]);
+    }
+    if constexpr (EPI == EPI_LOGITS) Q3_PIN_S(a.argmax_slots);
+    // the activation / norm-weight loads go out before anything else is computed (they are the critical path)
+    ProRegs<PRO> pr;
+    unsigned long long etv = 0ull;
+    if (EPI == EPI_SWIGLU && threadIdx.x < 32) etv = kExp2Tab[threadIdx.x];   // oldest load: retires first (vmcnt is in order)
+    gemv_prologue_issue<PRO>(a, pr);
+    __builtin_amdgcn_sched_barrier(0);        // (pin the issue order: vmcnt retires in order)
     constexpr bool kStage = (PRO == PRO_NORM || PRO == PRO_EMBED_NORM);
     constexpr int HU = (EPI == EPI_SWIGLU) ? (RU / 2) : RU;   // rows per run
     static_assert(EPI != EPI_SWIGLU || RU >= 2, "SwiGLU tiles hold a w1 and a w3 row");
@@ -974,11 +999,6 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
     const bool any = cb < nb;
     Tile<RU, JU> TA, TB;
     RowSrc RA, RB;
-    ProRegs<PRO> pr;
-    unsigned long long etv = 0ull;
-    if (EPI == EPI_SWIGLU && threadIdx.x < 32) etv = kExp2Tab[threadIdx.x];   // oldest load: retires first (vmcnt is in order)
-    gemv_prologue_issue<PRO>(a, pr);          // activation / norm-weight loads go out first ...
-    __builtin_amdgcn_sched_barrier(0);        // (pin the issue order: vmcnt retires in order)
     RA = batch_rows(min(cb, nb - 1));         // (idle waves re-read a valid batch; nothing is stored)
     load_tile(TA, RA, 0);                     // ... then the first weight tile ...
     int pb = cb, pjt = 1;                     // PF: coordinates of the tile preloaded into TB
@@ -1473,6 +1493,9 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float att_p[kShortMaxT];   // probabilities
     __shared__ unsigned long long etab[32];                            // exp2 table of q3_expf, staged once
     ATTS_STAMP(0, 0);
+    Q3_PIN_S(a.st); Q3_PIN_S(a.pos_override); Q3_PIN_S(a.q); Q3_PIN_S(a.k_raw); Q3_PIN_S(a.key_cache); Q3_PIN_S(a.value_cache);
+    Q3_PIN_S(a.q_norm_w); Q3_PIN_S(a.k_norm_w); Q3_PIN_S(a.rope); Q3_PIN_S(a.xb); Q3_PIN_S(a.n_heads); Q3_PIN_S(a.n_kv_heads);
+    Q3_PIN_S(a.write_q);
 
     const int h = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
