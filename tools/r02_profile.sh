@@ -12,14 +12,14 @@ ck.ensure_synthetic_checkpoint("/tmp/qwen3-8b-seed1236.q3bin", ck.SHAPES["qwen3-
 PYEOF
 what=${2:-all}
 if [ $what = all ] || [ $what = bench ]; then
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench -o b -- $PY bench.py --worker --steps 128 --warmup 8 > $out/bench_worker.json 2> $out/bench_worker.err
+Q3_EAGER_LAUNCH=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench -o b -- $PY bench.py --worker --steps 128 --warmup 8 > $out/bench_worker.json 2> $out/bench_worker.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o p -- $PY bench.py --worker --steps 8 --warmup 2 > /dev/null 2> $out/pmc_fetch.err
 fi
 if [ $what = all ] || [ $what = chat ]; then
 Q3_EAGER_LAUNCH=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/chat -o c -- $PY tools/bench_chat.py --decode 128 > $out/chat.json 2> $out/chat.err
 fi
 if [ $what = all ] || [ $what = batch ]; then
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/batch -o b -- $PY tools/bench_batch.py --steps 32 --verify 0 > $out/batch.json 2> $out/batch.err
+Q3_EAGER_LAUNCH=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/batch -o b -- $PY tools/bench_batch.py --steps 32 --verify 0 > $out/batch.json 2> $out/batch.err
 rocprofv3 -L > $out/counters.txt 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $out/pmc_mfma -o m -- $PY tools/bench_batch.py --steps 8 --verify 0 > /dev/null 2> $out/pmc_mfma.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch_batch -o p -- $PY tools/bench_batch.py --steps 8 --verify 0 > /dev/null 2> $out/pmc_fetch_batch.err
