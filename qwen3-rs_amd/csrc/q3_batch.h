@@ -105,6 +105,83 @@ __global__ __launch_bounds__(kWG) void k_bquant(const GemvArgs a0, const BQuantA
     for (int g = threadIdx.x; g < ng; g += kWG) b.xs_p[((size_t)nt * ng + g) * 16 + s] = sm.xs[g];
 }
 
+// The same prologue spread over `gridDim.x` workgroups per stream (PRO_NORM / PRO_QUANT).  The exact sum of squares is
+// the only part that needs the whole vector -- every part recomputes it (one 32-workgroup launch was latency-bound:
+// 8-10 us for a few hundred KB) -- while the normalise / divide / round / pack work, which is instruction-issue bound
+// (~110 instructions per float4), is cut into slices of whole quantization groups.  Same arithmetic per element as
+// k_bquant, so the packed operands are identical.
+template <int PRO>
+__global__ __launch_bounds__(kWG) void k_bquant_split(const GemvArgs a, const BQuantArgs b) {
+    static_assert(PRO == PRO_NORM || PRO == PRO_QUANT, "embedding rows keep the single-workgroup kernel");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int sidx = blockIdx.y, part = blockIdx.x, nparts = gridDim.x;
+    const int tid = threadIdx.x;
+    const int n = a.n, G = a.group, nv = n >> 2, glanes = G >> 2;
+    const int nvp = nv / nparts;                       // float4 slots of this part (a whole number of groups: host)
+    const int v0 = part * nvp;
+    const v4f* x4 = (const v4f*)(a.in + (size_t)sidx * b.in_stride);
+    char* base = smem_raw;
+    float f = 1.0f;
+    // this part's slots are requested first, then (PRO_NORM) the whole vector for the sum of squares
+    const int nk = (nvp + kWG - 1) / kWG;              // <= 2 for every listed shape
+    v4f xv[2], wv[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int v = v0 + min(k * kWG + tid, nvp - 1);
+        xv[k] = x4[v];
+        if (PRO == PRO_NORM) wv[k] = ((const v4f*)a.norm_w)[v];
+    }
+    if (PRO == PRO_NORM) {
+        float* sq = (float*)base;                      // term_floats(n) squares in the exact-sum layout
+        float* red = sq + term_floats(n);              // 64 floats
+        base += 4 * (size_t)(term_floats(n) + 64);
+        float part_sum = 0.0f;
+        for (int v = tid; v < nv; v += kWG) {
+            const v4f t = x4[v];
+            v4f q2;
+            q2.x = t.x * t.x; q2.y = t.y * t.y; q2.z = t.z * t.z; q2.w = t.w * t.w;   // layers.rs:113
+            *(v4f*)(sq + term_index(4 * v, n)) = q2;
+            part_sum = part_sum + sumsq4(t);
+        }
+        float ss;
+        if (a.strict) {
+            __syncthreads();
+            ss = seq_sum_terms(sq, n);
+        } else {
+            ss = block_sum_fast(part_sum, red);
+        }
+        f = 1.0f / sqrtf(ss / (float)n + kEps);
+    }
+    int8_t* xq = (int8_t*)base;                        // this part's quantized slice
+    float* xs = (float*)(base + align16((size_t)nvp * 4));
+    for (int k = 0; k < nk; ++k) {
+        const int vl = k * kWG + tid;                  // slot inside the part
+        const bool valid = vl < nvp;
+        v4f y = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+            v4f t = xv[0], w = wv[0];
+            if (k == 1) { t = xv[1]; w = wv[1]; }
+            if (k >= 2) { t = x4[v0 + vl]; if (PRO == PRO_NORM) w = ((const v4f*)a.norm_w)[v0 + vl]; }
+            y = (PRO == PRO_NORM) ? norm4(w, f, t) : t;
+        }
+        quantize4_to_lds(y, vl, glanes, valid, xq, xs);
+    }
+    __syncthreads();
+    // packed MFMA operand order (see k_bquant): 16-byte pieces of this part
+    const int ng = n / G, nj = G >> 6;
+    const int nt = sidx >> 4, s = sidx & 15;
+    for (int pl = tid; pl < (nvp >> 2); pl += kWG) {
+        const int p = (v0 >> 2) + pl;
+        const int k0 = p << 4;
+        const int g = k0 / G, within = (k0 % G) >> 4;
+        const int q = within / nj, j = within % nj;
+        const size_t dst = ((((size_t)nt * ng + g) * nj + j) * 64 + (q * 16 + s)) * 16;
+        *(v4i*)(b.xq_p + dst) = ((const v4i*)xq)[pl];
+    }
+    const int g0 = (v0 * 4) / G, ngp = (nvp * 4) / G;
+    for (int gl = tid; gl < ngp; gl += kWG) b.xs_p[((size_t)nt * ng + g0 + gl) * 16 + s] = xs[gl];
+}
+
 // ------------------------------------------------------------------------------------------------
 // Batched W8A8 matmul on the matrix cores.
 // ------------------------------------------------------------------------------------------------
@@ -224,6 +301,8 @@ __global__ __launch_bounds__(kBThreads) void k_bgemm(const BGemmArgs a) {
         // ---- MFMA: this wave's GW groups of the phase -> f32 terms in LDS.  Each group's fragment registers are
         // re-requested for the next phase as soon as its MFMAs have read them: the loads trickle through the CU's
         // texture path during the math instead of arriving as one burst from all 16 waves after it.
+        // (Tried in round 2 and dropped: a second fragment set for the one-tile tasks, the whole next phase requested
+        // before the first MFMA -- wo/w2 unchanged at 14.3 -> 14.6 us, QKV 12.5 -> 15.0 us through the lost occupancy.)
         if (more) issue_scales(nxt, ntask, np);
 #pragma unroll
         for (int k = 0; k < GW; ++k) {
