@@ -438,8 +438,8 @@ __global__ __launch_bounds__(kBThreads) void k_bgemm(const BGemmArgs a) {
 // sum is walked in the reference order (layers.rs:346-419,495-506), so the result is bit-identical to k_attn in
 // reference-order mode; Q3_FLAG_FAST engines use this exact path too (exact is always admissible).
 // ------------------------------------------------------------------------------------------------
-constexpr int kGqaTch = 128;            // most timesteps staged per LDS round
-constexpr int kGqaSlots = 16;           // float4 staging registers per thread (tch*hd/4 <= slots * threads)
+constexpr int kGqaTch = 64;             // most timesteps staged per LDS round (one score dot per lane and chunk)
+constexpr int kGqaSlots = 8;            // float4 staging registers per thread (tch*hd/4 <= slots * threads); 16 made the kernel spill
 __host__ __device__ inline int gqa_att_stride(int seq_len) { return (seq_len + 255) & ~255; }
 // timesteps per round: the workgroup's (kv_mul + 1) * 64 threads hold a chunk in kGqaSlots float4 registers each
 __host__ __device__ inline int gqa_tch(int hd, int kv_mul) {
@@ -452,8 +452,14 @@ __host__ __device__ inline size_t attn_gqa_smem_bytes(int hd, int kv_mul, int se
     return 4 * (nw * hd * 3 + (size_t)kv_mul * gqa_att_stride(seq_len) + (size_t)gqa_tch(hd, kv_mul) * (hd + kKPad));
 }
 
+#ifdef Q3_DEV
+#define GQA_STAMP(i) do { if (a0.stamps != nullptr && blockIdx.x == 3 && blockIdx.y == gridDim.y - 1 && threadIdx.x == 0) a0.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GQA_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(512) void k_attn_gqa(const AttnArgs a0) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    GQA_STAMP(0);
     const int hd = a0.hd, kv_mul = a0.n_heads / a0.n_kv_heads, nw = kv_mul + 1;
     const int kvh = blockIdx.x;
     const size_t sbi = blockIdx.y;
@@ -498,12 +504,12 @@ __global__ __launch_bounds__(512) void k_attn_gqa(const AttnArgs a0) {
         const int total = cnt << q4s;
 #pragma unroll
         for (int u = 0; u < kGqaSlots; ++u) {
-            const int idx = tid + u * nthr;
-            if (u * nthr < total) {                // wave-uniform
-                const int ii = min(idx, total - 1);
-                const int row = ii >> q4s, c = ii & ((1 << q4s) - 1);
-                sr[u] = *(const v4f*)(gbase + (size_t)(t0 + row) * kvd + 4 * c);
-            }
+            // unconditional: slots past the chunk re-read its last float4.  (A per-slot `if` put every load in its own
+            // basic block; with the spills that followed, hipcc waited for each load before issuing the next -- 8,000 cycles
+            // to request one 64 KB chunk, measured with the dev stamps.)
+            const int ii = min(tid + u * nthr, total - 1);
+            const int row = ii >> q4s, c = ii & ((1 << q4s) - 1);
+            sr[u] = *(const v4f*)(gbase + (size_t)(t0 + row) * kvd + 4 * c);
         }
     };
     auto stage_commit_g = [&](int ld, int t0, int cnt, int skip) {
@@ -533,15 +539,20 @@ __global__ __launch_bounds__(512) void k_attn_gqa(const AttnArgs a0) {
         for (int i = lane; i < hd; i += 64) krow[i] = k_s[i];
     }
     const float scale = 1.0f / sqrtf((float)hd);   // (head_dim as f32).sqrt().recip()
+    GQA_STAMP(1);
 
     // ---- scores: att[t] = (q . K[t]) * scale                                   layers.rs:391-401
     for (int c = 0; c < nch; ++c) {
         const int t0 = c * tch, cnt = min(tch, np - t0);
+        if (c == 8) GQA_STAMP(8);
         stage_commit_g(kld, t0, cnt, own_k ? pos : -1);
         if (own_k && pos >= t0 && pos < t0 + cnt)  // the current position's K comes from this kernel, not the cache
             for (int i = tid; i < hd; i += nthr) buf[(pos - t0) * kld + i] = k_s[i];
+        if (c == 8) GQA_STAMP(9);
         __syncthreads();
+        if (c == 8) GQA_STAMP(10);
         if (c + 1 < nch) stage_issue_g(kbase, t0 + tch, min(tch, np - t0 - tch));     // next chunk under the dots
+        if (c == 8) GQA_STAMP(11);
         if (!kwave) {
             const v4f* q4 = (const v4f*)(q_s + wave * hd);
             for (int t = lane; t < cnt; t += 64) {
@@ -549,12 +560,12 @@ __global__ __launch_bounds__(512) void k_attn_gqa(const AttnArgs a0) {
                 float dot = -0.0f;
                 const int nq = hd >> 2;
                 int i = 0;
-                for (; i + 16 <= nq; i += 16) {
-                    v4f kk[16], qq[16];
+                for (; i + 8 <= nq; i += 8) {          // 8 float4 of K and q at a time: 64 registers (16 at a time spilled)
+                    v4f kk[8], qq[8];
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) { kk[u] = k4[i + u]; qq[u] = q4[i + u]; }
+                    for (int u = 0; u < 8; ++u) { kk[u] = k4[i + u]; qq[u] = q4[i + u]; }
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) {
+                    for (int u = 0; u < 8; ++u) {
                         float p = qq[u].x * kk[u].x; dot = dot + p;
                         p = qq[u].y * kk[u].y; dot = dot + p;
                         p = qq[u].z * kk[u].z; dot = dot + p;
@@ -571,9 +582,11 @@ __global__ __launch_bounds__(512) void k_attn_gqa(const AttnArgs a0) {
                 att[t0 + t] = dot * scale;
             }
         }
+        if (c == 8) GQA_STAMP(12);
         __syncthreads();                           // chunk consumed before the next one lands in buf
+        if (c == 8) GQA_STAMP(13);
     }
-    stage_issue_g(vbase, 0, min(tch, np));         // V chunk 0 under the softmax
+    GQA_STAMP(2);
 
     // ---- softmax, one wave per head                                            layers.rs:495-506
     if (!kwave) {
@@ -597,6 +610,10 @@ __global__ __launch_bounds__(512) void k_attn_gqa(const AttnArgs a0) {
         wave_lds_sync();
     }
 
+    GQA_STAMP(3);
+    // (V chunk 0 is requested only now: holding its 16 float4 staging registers across the softmax -- whose exact sum keeps
+    // up to 64 registers of terms -- made the kernel spill, and hipcc then waits on every staging load individually)
+    stage_issue_g(vbase, 0, min(tch, np));
     // ---- xb = sum_t att[t] * V[t]  (fill(0.0) then += in t order)              layers.rs:406-417
     float o[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int c = 0; c < nch; ++c) {
@@ -655,6 +672,7 @@ __global__ __launch_bounds__(512) void k_attn_gqa(const AttnArgs a0) {
         }
         __syncthreads();
     }
+    GQA_STAMP(4);
     if (!kwave) {
         float* out = a0.xb + sbi * a0.sb_xb + (size_t)h * hd;
 #pragma unroll

@@ -811,7 +811,9 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
     const int units = (EPI == EPI_SWIGLU) ? a.seg[0].rows : a.total_rows;   // rows (or hidden units)
     //   // rows (or hidden units)
     const int nb = (units + HU - 1) / HU;
-    const int pos = (EPI == EPI_QKV) ? a.st->pos : 0;
+    // (readfirstlane: the value is wave-uniform, but a vector load lands in a VGPR and every address / branch derived from it
+    // would be computed per lane)
+    const int pos = (EPI == EPI_QKV) ? __builtin_amdgcn_readfirstlane(a.st->pos) : 0;
 
     // QKV: segments 1,2 are addressed as byte deltas from segment 0 and blended with 0/1 arithmetic (a
     // select between pointers loaded from the kernarg segment gets folded by LLVM into a VECTOR load of
@@ -1249,7 +1251,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a) {
     const int kv_mul = a.n_heads / a.n_kv_heads;
     const int kvh = h / kv_mul;
     const size_t kvd = (size_t)a.n_kv_heads * hd;
-    const int pos = a.pos_override >= 0 ? a.pos_override : a.st->pos;
+    const int pos = __builtin_amdgcn_readfirstlane(a.pos_override >= 0 ? a.pos_override : a.st->pos);   // wave-uniform -> SGPR
     float* att = a.att_global ? a.att_global + (size_t)h * a.seq_len : att_l;
     const float* cs = a.rope + (size_t)pos * hd;  // hd/2 (cos,sin) pairs
     const float* kbase = a.key_cache + (size_t)kvh * hd;
@@ -1458,22 +1460,26 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Short-context attention (pos < 256, head_dim 64 or 128): one 4-wave workgroup per query head, NO K/V staging in LDS.
-//   * wave w owns timesteps [64w, 64w+64): lane t keeps its K row in registers (HD/4 dwordx4 loads issued at entry, in
-//     flight under the norm) and walks the reference's sequential dot (layers.rs:395-400) against q broadcast from LDS;
-//     the current position's key comes from this kernel (LDS), selected per lane;
-//   * waves 0/1 meanwhile do the QK-RMSNorm + RoPE of q / k (layers.rs:346-372);
-//   * after ONE barrier on the scores every wave reads them back 4 per lane and does the softmax redundantly (max,
-//     glibc expf, the sequential sum as one chain over LDS for <= 128 timesteps, the speculative scan beyond); every
-//     wave writes the SAME values to the e / p rows, so no barrier separates a wave's own write from its own read;
-//   * the last HD/64 waves own the output elements: V[t][e] arrives by coalesced 4-byte loads (32 timesteps per register
-//     set, double buffered, first two sets requested at entry) and the chain o += p_t * v_t runs in t order
-//     (layers.rs:406-417) with p broadcast from LDS four timesteps per read.
+// Short-context attention (pos < 256, head_dim 64 or 128): one 4-wave workgroup per query head, NO K/V staging in LDS,
+// and the waves split by ROLE so that each role's registers hold only what it needs:
+//   * score waves (the first 4 - HD/64): wave w owns timesteps 64w + lane (a second pass covers contexts beyond
+//     64 x #score waves): lane t keeps its K row in registers (HD/4 dwordx4 loads issued at entry, in flight under the
+//     norm) and walks the reference's sequential dot (layers.rs:395-400) against q broadcast from LDS; the current
+//     position's key comes from this kernel (LDS).  Waves 0/1 first do the QK-RMSNorm + RoPE of q / k
+//     (layers.rs:346-372);
+//   * output waves (the last HD/64): lane = output element.  V[t][e] arrives by coalesced 4-byte loads into FIVE register
+//     sets of 32 timesteps, all requested at kernel entry -- a context of up to 160 positions is completely in flight
+//     before the scores exist (two sets were not enough: folding 32 timesteps takes ~320 cycles, an HBM round trip
+//     ~2,000, and the launch period jumped from 5.2 to 7.4 us past position 64).  After the scores barrier every
+//     wave reads them back 4 per lane for the max; the score waves take the exp of their own timesteps; the output waves
+//     then run the softmax denominator (one chain over LDS for <= 128 timesteps, the speculative scan beyond), the
+//     probabilities, and the chain o += p_t * v_t in t order (layers.rs:406-417) with p as LDS float4 bursts.
 // Every sum is in the reference's order => bit-identical to k_attn / the CPU path.  Used in both modes (the default mode's
 // tolerance is trivially met).  Measured cost of the pieces (tools/sum_probe.hip): a dependent v_add 10 cycles, a DPP
 // hop 17, v_readlane + add 23 -- which is why the long chains read their operands from LDS/VGPRs, never cross-lane.
 // ------------------------------------------------------------------------------------------------
 constexpr int kShortMaxT = 256;
+constexpr int kShortVSets = 5;       // register sets of 32 timesteps per output wave
 #ifdef Q3_DEV
 #define ATTS_STAMP(i, thr) do { if (a.stamps != nullptr && blockIdx.x == 3 && (int)threadIdx.x == (thr)) a.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -1484,7 +1490,9 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
     static_assert(HD == 64 || HD == 128, "head dims instantiated");
     constexpr int NQ4 = HD / 4;          // float4 per K row
     constexpr int HALF = HD / 2;         // rotate-half pairing (i, i + HD/2)
-    constexpr int NVW = HD / 64;         // waves that own output elements (the last NVW of the workgroup)
+    constexpr int NVW = HD / 64;         // output waves (the last NVW of the workgroup)
+    constexpr int NSW = 4 - NVW;         // score waves
+    constexpr int TPP = 64 * NSW;        // timesteps per score pass
     __shared__ __attribute__((aligned(16))) float q_s[HD];
     __shared__ __attribute__((aligned(16))) float k_s[HD];
     __shared__ __attribute__((aligned(16))) float sq_s[2 * HD];        // squares of raw q | raw k
@@ -1493,6 +1501,8 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float att_p[kShortMaxT];   // probabilities
     __shared__ unsigned long long etab[32];                            // exp2 table of q3_expf, staged once
     ATTS_STAMP(0, 0);
+    if (Q3_DEV_ABLATE(a, 16) && blockIdx.x != 3) return;      // developer: one workgroup only (launch-period experiments)
+    if (Q3_DEV_ABLATE(a, 32)) return;                         // developer: empty kernel with this kernel's resources
     Q3_PIN_S(a.st); Q3_PIN_S(a.pos_override); Q3_PIN_S(a.q); Q3_PIN_S(a.k_raw); Q3_PIN_S(a.key_cache); Q3_PIN_S(a.value_cache);
     Q3_PIN_S(a.q_norm_w); Q3_PIN_S(a.k_norm_w); Q3_PIN_S(a.rope); Q3_PIN_S(a.xb); Q3_PIN_S(a.n_heads); Q3_PIN_S(a.n_kv_heads);
     Q3_PIN_S(a.write_q);
@@ -1503,14 +1513,89 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
     const int kv_mul = a.n_heads / a.n_kv_heads;
     const int kvh = h / kv_mul;
     const size_t kvd = (size_t)a.n_kv_heads * HD;
-    const int pos = a.pos_override >= 0 ? a.pos_override : a.st->pos;
+    const int pos = __builtin_amdgcn_readfirstlane(a.pos_override >= 0 ? a.pos_override : a.st->pos);   // wave-uniform -> SGPR
     const int np = pos + 1;
     const float* kbase = a.key_cache + (size_t)kvh * HD;
     const float* vbase = a.value_cache + (size_t)kvh * HD;
+    const int t4 = 4 * lane;                              // softmax read-back: lane l looks at timesteps 4l .. 4l+3
 
-    // ---- everything this workgroup will read is requested up front
-    unsigned long long etv = 0ull;
-    if (tid >= kWG - 32) etv = kExp2Tab[tid - (kWG - 32)];
+    if (wave >= NSW) {
+        // ================================ output waves ================================
+        const int e = 64 * (wave - NSW) + lane;           // output element of this lane
+        float vv[kShortVSets][32];
+        auto v_issue = [&](float (&R)[32], int c) {
+            // rows past the context re-read row pos (finite: written by the QKV launch); their probability is +0.0
+            const float* vp = vbase + e;
+#pragma unroll
+            for (int u = 0; u < 32; ++u) R[u] = vp[(size_t)min(32 * c + u, pos) * kvd];
+        };
+        unsigned long long etv = 0ull;
+        if (tid >= kWG - 32) etv = kExp2Tab[tid - (kWG - 32)];
+        // A wave can have 63 vector loads outstanding: the first two sets go out now, the rest behind barrier A -- by then
+        // the first loads have returned, and the score waves are not held up at the barrier by this wave's issue stalls
+        // (requesting all five sets up front pushed barrier A from 4,300 to 10,000 cycles at position 130).
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            if (32 * c < np) v_issue(vv[c], c);           // wave-uniform
+        if (tid >= kWG - 32) etab[tid - (kWG - 32)] = etv;
+        __syncthreads();                                  // A: q_s / k_s / etab (this role only publishes etab)
+#pragma unroll
+        for (int c = 2; c < kShortVSets; ++c)
+            if (32 * c < np) v_issue(vv[c], c);           // a context of <= 160 positions is all in flight before the scores exist
+        __syncthreads();                                  // B: scores
+        __syncthreads();                                  // C: exp(score - max)
+        ATTS_STAMP(5, kWG - 64);
+        // softmax denominator (layers.rs:495-506), probabilities
+        const v4f e4 = ((const v4f*)att_e)[lane];
+        float sum;
+        if (np <= 128) {
+            // one chain over the (zero padded) row: np adds of 10 cycles, operands streamed from LDS as float4
+            sum = seq_chain(-0.0f, (const v4f*)att_e, (np + 3) >> 2);
+        } else {
+            const float etot = (e4.x + e4.y) + (e4.z + e4.w);
+            sum = spec_sum_lanes(etot, (np + 3) >> 2, [&](float s) { return chain4(s, e4); });
+        }
+        const float inv = 1.0f / sum;
+        v4f p4;
+        p4.x = e4.x * inv; p4.y = e4.y * inv; p4.z = e4.z * inv; p4.w = e4.w * inv;
+        ((v4f*)att_p)[lane] = p4;                         // both output waves write the same values; 0 past the context
+        wave_lds_sync();
+        // xb = sum_t att[t] * V[t], one chain per output element in t order          layers.rs:406-417
+        float o = 0.0f;
+        auto fold_chunk = [&](const float (&R)[32], int c) {
+            const v4f* pp = (const v4f*)att_p + 8 * c;
+            v4f pq[8];
+#pragma unroll
+            for (int u4 = 0; u4 < 8; ++u4) pq[u4] = pp[u4];   // one burst of LDS reads, not one round trip per step
+#pragma unroll
+            for (int u4 = 0; u4 < 8; ++u4) {
+                if (32 * c + 4 * u4 < np) {               // wave-uniform: the chain stops at the context's last float4
+                    // past the context (inside the last float4) p = +0.0 and R holds the finite row pos again: the term
+                    // is +-0.0 and o + (+-0.0) == o (o starts from +0.0 and is never -0.0)
+                    const v4f pv = pq[u4];
+                    float pr = pv.x * R[4 * u4 + 0]; o = o + pr;
+                    pr = pv.y * R[4 * u4 + 1]; o = o + pr;
+                    pr = pv.z * R[4 * u4 + 2]; o = o + pr;
+                    pr = pv.w * R[4 * u4 + 3]; o = o + pr;
+                }
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < kShortVSets; ++c)
+            if (32 * c < np) fold_chunk(vv[c], c);
+        // contexts beyond 160 positions (never inside the 128-token benchmark run): the remaining chunks go through set 0 / 1
+        for (int c = kShortVSets; 32 * c < np; c += 2) {
+            v_issue(vv[0], c);
+            if (32 * (c + 1) < np) v_issue(vv[1], c + 1);
+            fold_chunk(vv[0], c);
+            if (32 * (c + 1) < np) fold_chunk(vv[1], c + 1);
+        }
+        a.xb[(size_t)h * HD + e] = o;
+        ATTS_STAMP(6, kWG - 64);
+        return;
+    }
+
+    // ================================ score waves ================================
     const bool is_q = wave == 0, is_k = wave == 1;
     float r_lo = 0.f, r_hi = 0.f, w_lo = 0.f, w_hi = 0.f, rc = 0.f, rs = 0.f;
     if (wave < 2) {
@@ -1525,30 +1610,17 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
         rc = cs[2 * i];
         rs = cs[2 * i + 1];
     }
-    const int t = 64 * wave + lane;
-    const bool wave_has_t = 64 * wave < np;               // wave-uniform
+    int t = 64 * wave + lane;                             // first pass
     v4f kr[NQ4];
-    if (wave_has_t) {
+    auto k_issue = [&](int tt) {
         // rows past the context re-read row pos (one cache line for all of them); row pos itself still holds whatever
         // an earlier pass left there -- both are replaced / masked below
-        const v4f* kp = (const v4f*)(kbase + (size_t)min(t, pos) * kvd);
+        const v4f* kp = (const v4f*)(kbase + (size_t)min(tt, pos) * kvd);
 #pragma unroll
         for (int i = 0; i < NQ4; ++i) kr[i] = kp[i];
-    }
-    const bool is_v = wave >= 4 - NVW;                    // wave-uniform
-    const int e = 64 * (wave - (4 - NVW)) + lane;         // output element of this lane (V waves)
-    float va[32], vb[32];
-    auto v_issue = [&](float (&R)[32], int c) {
-        const float* vp = vbase + e;
-#pragma unroll
-        for (int u = 0; u < 32; ++u) R[u] = vp[(size_t)min(32 * c + u, pos) * kvd];
     };
-    if (is_v) {
-        v_issue(va, 0);
-        if (np > 32) v_issue(vb, 1);
-    }
+    if (64 * wave < np) k_issue(t);
     ATTS_STAMP(1, 0);
-    if (tid >= kWG - 32) etab[tid - (kWG - 32)] = etv;
 
     // ---- waves 0/1: RMSNorm (layers.rs:109-119) + RoPE (layers.rs:173-185) of q / k
     if (wave < 2) {
@@ -1581,13 +1653,20 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
         }
     }
     ATTS_STAMP(2, 0);
-    __syncthreads();
+    __syncthreads();                                      // A
     ATTS_STAMP(3, 0);
 
     // ---- scores: att[t] = (q . K[t]) * scale, the dot walked in index order       layers.rs:391-401
     const float scale = 1.0f / sqrtf((float)HD);
-    float sc = -__builtin_inff();
-    if (wave_has_t) {
+    float sc0 = -__builtin_inff(), sc1 = -__builtin_inff();
+    for (int pass = 0; pass < 2; ++pass) {
+        const int tb = TPP * pass + 64 * wave;            // wave-uniform first timestep of this wave in this pass
+        t = tb + lane;
+        if (tb >= np) {                                   // nothing to score: the slots still get their -inf
+            if (t < kShortMaxT) att[t] = -__builtin_inff();
+            continue;
+        }
+        if (pass == 1) k_issue(t);                        // contexts beyond one pass: rows requested now
         if (t == pos) {                                   // one lane of one wave: the current position's key is in LDS
 #pragma unroll
             for (int i = 0; i < NQ4; ++i) kr[i] = ((const v4f*)k_s)[i];
@@ -1602,73 +1681,35 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
             p = qv.z * kk.z; dot = dot + p;
             p = qv.w * kk.w; dot = dot + p;
         }
-        if (t < np) sc = dot * scale;
+        const float sc = t < np ? dot * scale : -__builtin_inff();
+        if (t < kShortMaxT) att[t] = sc;                  // all 256 slots are written: -inf beyond the context
+        if (pass == 0) sc0 = sc; else sc1 = sc;
     }
-    att[t] = sc;                                          // all 256 slots are written: -inf beyond the context
-    __syncthreads();
+    __syncthreads();                                      // B
     ATTS_STAMP(4, 0);
 
-    // ---- softmax (layers.rs:495-506): the max in every wave (4 scores per lane), exp of the wave's own timesteps
+    // ---- softmax numerators (layers.rs:495-506): the max from 4 scores per lane, exp of this wave's own timesteps
     const v4f s4 = ((const v4f*)att)[lane];
     float m = fmaxf(fmaxf(s4.x, s4.y), fmaxf(s4.z, s4.w));
     m = group_max_f32(m, 64);
-    float ev = 0.0f;
-    if (wave_has_t) {
-        ev = q3_expf_t(t < np ? sc - m : 0.0f, etab);
-        ev = t < np ? ev : 0.0f;                          // +0.0 past the context: leaves every partial sum unchanged
-    }
-    att_e[t] = ev;
-    __syncthreads();
-    ATTS_STAMP(5, kWG - 64);
-
-    // ---- the waves that own output elements: softmax denominator, probabilities, then
-    //      xb = sum_t att[t] * V[t], one chain per output element in t order          layers.rs:406-417
-    if (is_v) {
-        const v4f e4 = ((const v4f*)att_e)[lane];
-        float sum;
-        if (np <= 128) {
-            // one chain over the (zero padded) row: np adds of 10 cycles, operands streamed from LDS as float4
-            sum = seq_chain(-0.0f, (const v4f*)att_e, (np + 3) >> 2);
-        } else {
-            const float etot = (e4.x + e4.y) + (e4.z + e4.w);
-            sum = spec_sum_lanes(etot, (np + 3) >> 2, [&](float s) { return chain4(s, e4); });
-        }
-        const float inv = 1.0f / sum;
-        v4f p4;
-        p4.x = e4.x * inv; p4.y = e4.y * inv; p4.z = e4.z * inv; p4.w = e4.w * inv;
-        ((v4f*)att_p)[lane] = p4;                         // both V waves write the same values; 0 past the context
-        wave_lds_sync();
-        float o = 0.0f;
-        auto fold_chunk = [&](const float (&R)[32], int c) {
-            const v4f* pp = (const v4f*)att_p + 8 * c;
-            v4f pq[8];
+    (void)t4;
 #pragma unroll
-            for (int u4 = 0; u4 < 8; ++u4) pq[u4] = pp[u4];   // one burst of LDS reads, not one round trip per step
-#pragma unroll
-            for (int u4 = 0; u4 < 8; ++u4) {
-                if (32 * c + 4 * u4 < np) {               // wave-uniform: the chain stops at the context's last float4
-                    // past the context (inside the last float4) p = +0.0 and R holds the finite row pos again: the term
-                    // is +-0.0 and o + (+-0.0) == o (o starts from +0.0 and is never -0.0)
-                    const v4f pv = pq[u4];
-                    float pr = pv.x * R[4 * u4 + 0]; o = o + pr;
-                    pr = pv.y * R[4 * u4 + 1]; o = o + pr;
-                    pr = pv.z * R[4 * u4 + 2]; o = o + pr;
-                    pr = pv.w * R[4 * u4 + 3]; o = o + pr;
-                }
+    for (int pass = 0; pass < 2; ++pass) {
+        const int tb = TPP * pass + 64 * wave;
+        const int tt = tb + lane;
+        if (tt < kShortMaxT) {
+            float ev = 0.0f;                              // +0.0 past the context: leaves every partial sum unchanged
+            if (tb < np) {                                // wave-uniform
+                const float sc = pass == 0 ? sc0 : sc1;
+                ev = q3_expf_t(tt < np ? sc - m : 0.0f, etab);
+                ev = tt < np ? ev : 0.0f;
             }
-        };
-        for (int c = 0; 32 * c < np; c += 2) {
-            fold_chunk(va, c);
-            if (32 * (c + 2) < np) v_issue(va, c + 2);
-            if (32 * (c + 1) < np) {
-                fold_chunk(vb, c + 1);
-                if (32 * (c + 3) < np) v_issue(vb, c + 3);
-            }
+            att_e[tt] = ev;
         }
-        a.xb[(size_t)h * HD + e] = o;
     }
-    ATTS_STAMP(6, kWG - 64);
+    __syncthreads();                                      // C
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // Long-context attention (pos >= the host's split threshold): the same arithmetic, in the same order, spread
@@ -1710,7 +1751,7 @@ __global__ __launch_bounds__(kWG) void k_attn_scores(const AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kv_mul = a.n_heads / a.n_kv_heads, kvh = h / kv_mul;
     const size_t kvd = (size_t)a.n_kv_heads * hd;
-    const int pos = a.pos_override >= 0 ? a.pos_override : a.st->pos;
+    const int pos = __builtin_amdgcn_readfirstlane(a.pos_override >= 0 ? a.pos_override : a.st->pos);   // wave-uniform -> SGPR
     const int np = pos + 1;
     const int t0 = c * tch;
     if (t0 >= np) return;                              // chunks beyond the current position: nothing to do
@@ -1811,7 +1852,7 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kv_mul = a.n_heads / a.n_kv_heads, kvh = h / kv_mul;
     const size_t kvd = (size_t)a.n_kv_heads * hd;
-    const int pos = a.pos_override >= 0 ? a.pos_override : a.st->pos;
+    const int pos = __builtin_amdgcn_readfirstlane(a.pos_override >= 0 ? a.pos_override : a.st->pos);   // wave-uniform -> SGPR
     const int np = pos + 1;
     const int npad = (np + 255) & ~255;                  // whole 64 x (npad/64) blocks for the exact sum
     const float* src = a.att_global + (size_t)h * a.att_stride;
