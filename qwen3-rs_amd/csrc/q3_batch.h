@@ -457,10 +457,14 @@ __host__ __device__ inline size_t attn_gqa_smem_bytes(int hd, int kv_mul, int se
 #else
 #define GQA_STAMP(i) do { } while (0)
 #endif
+// HD_T / KVM_T: head_dim and kv_mul as compile-time constants for the listed models (128 with 2 or 4 query heads per kv
+// head) -- the staging index arithmetic (row = idx / (hd/4), ...) then folds to a pointer increment per slot; 0 = read
+// them from the arguments.
+template <int HD_T, int KVM_T>
 __global__ __launch_bounds__(512) void k_attn_gqa(const AttnArgs a0) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     GQA_STAMP(0);
-    const int hd = a0.hd, kv_mul = a0.n_heads / a0.n_kv_heads, nw = kv_mul + 1;
+    const int hd = HD_T ? HD_T : a0.hd, kv_mul = KVM_T ? KVM_T : a0.n_heads / a0.n_kv_heads, nw = kv_mul + 1;
     const int kvh = blockIdx.x;
     const size_t sbi = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = nw * 64;

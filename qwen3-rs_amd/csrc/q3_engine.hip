@@ -241,10 +241,25 @@ struct q3_engine {
 
 namespace {
 
+void launch_attn_out(const AttnArgs& aa, unsigned gx, unsigned gy, size_t smem, hipStream_t st) {
+    switch (aa.slice_w) {
+        case 8: hipLaunchKernelGGL(k_attn_out<8>, dim3(gx, gy), dim3(kWG), smem, st, aa); break;
+        case 16: hipLaunchKernelGGL(k_attn_out<16>, dim3(gx, gy), dim3(kWG), smem, st, aa); break;
+        case 32: hipLaunchKernelGGL(k_attn_out<32>, dim3(gx, gy), dim3(kWG), smem, st, aa); break;
+        default: hipLaunchKernelGGL(k_attn_out<0>, dim3(gx, gy), dim3(kWG), smem, st, aa); break;
+    }
+}
+int set_attn_out_smem(size_t bytes) {
+    int rc;
+    if ((rc = set_max_smem((const void*)k_attn_out<8>, bytes)) || (rc = set_max_smem((const void*)k_attn_out<16>, bytes)) ||
+        (rc = set_max_smem((const void*)k_attn_out<32>, bytes)) || (rc = set_max_smem((const void*)k_attn_out<0>, bytes))) return rc;
+    return Q3_OK;
+}
+
 void launch_one(const Launch& L, q3_engine* e) {
     if (L.is_attn) {
         if (L.attn_kind == 1) hipLaunchKernelGGL(k_attn_scores, dim3(L.grid, L.grid_y), dim3(kWG), L.smem, e->stream, L.aa);
-        else if (L.attn_kind == 2) hipLaunchKernelGGL(k_attn_out, dim3(L.grid, L.grid_y), dim3(kWG), L.smem, e->stream, L.aa);
+        else if (L.attn_kind == 2) launch_attn_out(L.aa, L.grid, L.grid_y, L.smem, e->stream);
         else if (L.attn_kind == 3) {
             if (L.aa.hd == 128) hipLaunchKernelGGL(k_attn_short<128>, dim3(L.grid), dim3(kWG), 0, e->stream, L.aa);
             else hipLaunchKernelGGL(k_attn_short<64>, dim3(L.grid), dim3(kWG), 0, e->stream, L.aa);
@@ -694,7 +709,7 @@ int q3_engine::build_plan() {
         B.aa.slice_w = slice_w;
         B.smem = attn_out_smem_bytes(hd, S, slice_w);
         if ((rc = set_max_smem((const void*)k_attn_scores, A.smem))) return rc;
-        if ((rc = set_max_smem((const void*)k_attn_out, B.smem))) return rc;
+        if ((rc = set_attn_out_smem(B.smem))) return rc;
         plan_long.push_back(A);
         plan_long.push_back(B);
     }
@@ -1266,10 +1281,10 @@ int q3_op_attention(float* xb, float* q, float* key_cache_layer, const float* va
         a.q_out = dqout.as<float>();
         const size_t sm1 = attn_scores_smem_bytes((int)head_dim), sm2 = attn_out_smem_bytes((int)head_dim, (int)seq_len, slice_w);
         a.slice_w = slice_w;
-        if ((rc = set_max_smem((const void*)k_attn_scores, sm1)) || (rc = set_max_smem((const void*)k_attn_out, sm2))) return rc;
+        if ((rc = set_max_smem((const void*)k_attn_scores, sm1)) || (rc = set_attn_out_smem(sm2))) return rc;
         const unsigned nchunk = (unsigned)((seq_len + attn_tch((int)head_dim) - 1) / attn_tch((int)head_dim));
         hipLaunchKernelGGL(k_attn_scores, dim3((unsigned)n_heads, nchunk), dim3(kWG), sm1, 0, a);
-        hipLaunchKernelGGL(k_attn_out, dim3((unsigned)n_heads, (unsigned)nsl), dim3(kWG), sm2, 0, a);
+        launch_attn_out(a, (unsigned)n_heads, (unsigned)nsl, sm2, 0);
         if ((rc = op_end())) return rc;
         HIP_TRY(hipMemcpy(dq.p, dqout.p, 4 * ahd, hipMemcpyDeviceToDevice));
     } else if ((head_dim == 64 || head_dim == 128) && env_int("Q3_ATT_SHORT", 1)) {

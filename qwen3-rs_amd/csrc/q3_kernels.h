@@ -452,6 +452,7 @@ __device__ __forceinline__ float seq_sum_blocks(const float* t, int nblk, int bl
     if (nq == 1) return seq_sum_blocks_regs<1>(t, nblk, stride, approx_tot);      // softmax rows <= 256
     if (nq == 2) return seq_sum_blocks_regs<2>(t, nblk, stride, approx_tot);
     if (nq == 8) return seq_sum_blocks_regs<8>(t, nblk, stride, approx_tot);
+    if (nq == 10) return seq_sum_blocks_regs<10>(t, nblk, stride, approx_tot);    // dim 2560 (the 4B shape): 40-term blocks
     const int j = threadIdx.x & 63;
     const bool live = j < nblk;
     const v4f* blk = (const v4f*)(t + (size_t)(live ? j : 0) * stride);
@@ -1190,10 +1191,10 @@ __device__ __forceinline__ void stage_issue(StageRegs& sr, const float* gbase, s
     const size_t stride = (size_t)rps * kvd;
 #pragma unroll
     for (int u = 0; u < kStageSlots; ++u) {
-        if (u * rps < cnt) {                            // wave-uniform: short contexts issue only the slots they need
-            const bool ok = r0 + u * rps < cnt;
-            sr.v[u] = *(const v4f*)(ok ? p + u * stride : p);   // tail rows re-read a valid address
-        }
+        // unconditional (rows past the chunk re-read its first row): a per-slot branch puts every load in its own basic block
+        // and hipcc then throttles the burst with conservative vmcnt waits (seen as `s_waitcnt vmcnt(6)` before every load)
+        const bool ok = r0 + u * rps < cnt;
+        sr.v[u] = *(const v4f*)(ok ? p + u * stride : p);
     }
 }
 // rows land at lds + r*ld; `skip` (absolute timestep or -1) is left untouched
@@ -1837,11 +1838,15 @@ __global__ __launch_bounds__(kWG) void k_attn_scores(const AttnArgs a) {
     }
 }
 
+// W_T: the slice width as a compile-time constant (8 / 16 / 32 cover every listed model; 0 = read a.slice_w): the staging
+// pass count and every index derived from it fold, and the per-slot `if (u < npass)` branches disappear -- each of them
+// put its load in a basic block of its own, which makes hipcc throttle the burst with conservative vmcnt waits.
+template <int W_T>
 __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     ATT_STAMP(0);
     const int hd = a.hd;
-    const int w = a.slice_w;                             // slice width (power of two >= 8, or hd)
+    const int w = W_T ? W_T : a.slice_w;                 // slice width (power of two >= 8, or hd)
     float* vbuf0 = (float*)smem_raw;                     // 2 x [kVChunk][w]  (reference order: [w][kVChunk + kVPad])
     float* pbuf0 = vbuf0 + 2 * (kVChunk + kVPad) * w;    // 2 x [kVChunk]
     float* red = pbuf0 + 2 * kVChunk;                    // [64]
@@ -1862,9 +1867,15 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
     const float* vbase = a.value_cache + (size_t)kvh * hd + (size_t)sl * w;
 
     const int w4s = __builtin_ctz(w >> 2);               // float4 per slice row = 1 << w4s
-    const int rps = kWG >> w4s;                          // rows per staging pass of the whole workgroup
-    const int npass = (kVChunk + rps - 1) / rps;         // <= 8 (w = 32) ... 2 (w = 8)
-    const int r0 = tid >> w4s, c4 = tid & ((1 << w4s) - 1);
+    // Reference-order mode with slices of 8 / 16 elements: the chain lanes live in wave 0, so wave 0 only folds and the
+    // other three waves do all the staging (a chunk still fits their 8 register slots); otherwise every thread stages.
+    const bool w0_folds = (W_T == 8 || W_T == 16) && a.strict;
+    const bool stager = !w0_folds || tid >= 64;          // wave-uniform
+    const int nst = w0_folds ? kWG - 64 : kWG;           // staging threads
+    const int sid = w0_folds ? max(tid - 64, 0) : tid;
+    const int rps = nst >> w4s;                          // rows per staging pass
+    const int npass = (kVChunk + rps - 1) / rps;         // <= 8
+    const int r0 = sid >> w4s, c4 = sid & ((1 << w4s) - 1);
     float o_s = 0.0f;
     v4f o_f = {0.f, 0.f, 0.f, 0.f};
     const int lpt = w >> 2, tpw = 64 / lpt;              // default mode: lanes per timestep / timesteps per wave step
@@ -1874,9 +1885,10 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
     struct VRegs { v4f v[8]; };
     VRegs vra, vrb;
     auto v_issue = [&](VRegs& R, int c0) {
+        if (!stager) return;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            if (u < npass) {
+            if (u < npass) {                             // (compile-time for the instantiated slice widths)
                 const int t = min(c0 + r0 + u * rps, np - 1);
                 R.v[u] = *(const v4f*)(vbase + (size_t)t * kvd + 4 * c4);
             }
@@ -1892,13 +1904,20 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
 
     // ---- softmax (layers.rs:495-506) into this workgroup's private probability row.  Scores are pulled 8 per thread at
     // a time (independent loads in flight together), twice: the second pass hits L1.
+    // The exact sum wants power-of-two blocks of <= 64 terms in registers, one lane each, read conflict-free: besides the
+    // contiguous row p[] a copy padded by 4 floats per block goes into the (still unused) first V tile.
+    int bl = 4;
+    while (64 * bl < np) bl <<= 1;                       // 4 .. 64 for np <= 4096
+    const bool padded = a.strict && bl <= 64;
+    const int blsh = __builtin_ctz(bl);
+    float* esc = vbuf0;                                  // (np/bl) x (bl + 4) floats <= 4352 <= one V tile of any slice width
     float m = -__builtin_inff();
-    for (int t0 = 0; t0 < np; t0 += 8 * kWG) {
-        float sv[8];
+    for (int t0 = 0; t0 < np; t0 += 16 * kWG) {          // 16 independent loads per thread in flight (np <= 4096: one trip)
+        float sv[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) sv[u] = src[min(t0 + u * kWG + tid, np - 1)];
+        for (int u = 0; u < 16; ++u) sv[u] = src[min(t0 + u * kWG + tid, np - 1)];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) m = fmaxf(m, sv[u]);
+        for (int u = 0; u < 16; ++u) m = fmaxf(m, sv[u]);
     }
     m = block_max(m, red);                               // (its barriers also publish etab)
     ATT_STAMP(1);
@@ -1915,6 +1934,7 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
                 e = t < np ? e : 0.0f;                   // +0.0 padding leaves every partial sum unchanged
                 part = part + e;
                 p[t] = e;
+                if (padded && t < (((np + bl - 1) >> blsh) << blsh)) esc[(t >> blsh) * (bl + kSpecPad) + (t & (bl - 1))] = e;
             }
         }
     }
@@ -1922,12 +1942,8 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
     ATT_STAMP(2);
     float sum;
     if (a.strict) {
-        // blocks of 4..64 terms (a power of two: straight-line register folds), one lane each; longer rows take 64 blocks
-        int bl = 4;
-        while (64 * bl < np) bl <<= 1;
-        if (bl <= 32) sum = seq_sum_blocks(p, (np + bl - 1) / bl, bl, bl, nullptr);    // np <= 2048
-        else sum = seq_sum_blocks(p, 64, npad >> 6, npad >> 6, nullptr);              // (64-term blocks at stride 64 floats would
-                                                                                      // read LDS 16-way bank conflicted)
+        if (padded) sum = seq_sum_blocks(esc, (np + bl - 1) >> blsh, bl, bl + kSpecPad, nullptr);
+        else sum = seq_sum_blocks(p, 64, npad >> 6, npad >> 6, nullptr);    // rows beyond 4096 positions: 64 longer blocks out of LDS
     } else sum = block_sum_fast(part, red);
     ATT_STAMP(3);
     const float inv = 1.0f / sum;
@@ -1939,6 +1955,7 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
     // ---- out[e] = sum_t p[t] * V[t][e]  (layers.rs:406-417), V slices staged kVChunk timesteps at a time
     constexpr int VLD = kVChunk + kVPad;
     auto v_commit = [&](const VRegs& R, int c0, int buf) {
+        if (!stager) return;
         float* vbuf = vbuf0 + buf * (kVChunk + kVPad) * w;
         float* pbuf = pbuf0 + buf * kVChunk;
 #pragma unroll
@@ -1960,7 +1977,7 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
                 *(v4f*)(vbuf + r * w + 4 * c4) = R.v[u];
             }
         }
-        for (int t = tid; t < kVChunk; t += kWG) pbuf[t] = (c0 + t < np) ? p[c0 + t] : 0.0f;
+        for (int t = sid; t < kVChunk; t += nst) pbuf[t] = (c0 + t < np) ? p[c0 + t] : 0.0f;
     };
     // fold chunk c0 out of LDS tile `buf` (committed one barrier earlier)
     auto fold = [&](int c0, int buf) {
