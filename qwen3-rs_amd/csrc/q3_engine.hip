@@ -124,6 +124,7 @@ typedef void (*GemvFn)(const GemvArgs);
 struct Launch {
     Family fam;
     bool is_attn = false, is_next = false;
+    int scores_kvm = 0;    // attn_kind 1: > 0 = k_attn_scores_kv<scores_kvm> (K chunk shared by the heads of a kv head)
     int attn_kind = 0;     // 0: single-kernel attention, 1: k_attn_scores, 2: k_attn_out (long-context split),
                            // 3: k_attn_short (pos < 256, head_dim 64/128: K rows in registers, no LDS staging)
     unsigned grid_y = 1;
@@ -256,9 +257,37 @@ int set_attn_out_smem(size_t bytes) {
     return Q3_OK;
 }
 
+
+// k_attn_scores_kv applies to head_dim 128 with 2 or 4 query heads per kv head (every listed Qwen3 size up to 8B)
+static int scores_kvm_for(int hd, int n_heads, int n_kv_heads) {
+    const int kv_mul = n_heads / n_kv_heads;
+    if (hd != kSgHd || (kv_mul != 2 && kv_mul != 4) || !env_int("Q3_ATT_SCORES_KV", 1)) return 0;
+    return kv_mul;
+}
+struct ScoresShape { int kvm; unsigned gx, gy; size_t smem; };
+static ScoresShape scores_shape(int hd, int n_heads, int n_kv_heads, int S) {
+    ScoresShape r;
+    r.kvm = scores_kvm_for(hd, n_heads, n_kv_heads);
+    const int tch = r.kvm == 4 ? sg_tch<4>() : r.kvm == 2 ? sg_tch<2>() : attn_tch(hd);
+    r.gx = (unsigned)(r.kvm ? n_kv_heads : n_heads);
+    r.gy = (unsigned)((S + tch - 1) / tch);
+    r.smem = r.kvm == 4 ? attn_scores_kv_smem_bytes<4>() : r.kvm == 2 ? attn_scores_kv_smem_bytes<2>() : attn_scores_smem_bytes(hd);
+    return r;
+}
+static int set_attn_scores_smem(const ScoresShape& sh) {
+    if (sh.kvm == 4) return set_max_smem((const void*)k_attn_scores_kv<4>, sh.smem);
+    if (sh.kvm == 2) return set_max_smem((const void*)k_attn_scores_kv<2>, sh.smem);
+    return set_max_smem((const void*)k_attn_scores, sh.smem);
+}
+static void launch_attn_scores(const AttnArgs& a, int kvm, unsigned gx, unsigned gy, size_t smem, hipStream_t st) {
+    if (kvm == 4) hipLaunchKernelGGL(k_attn_scores_kv<4>, dim3(gx, gy), dim3(kWG), smem, st, a);
+    else if (kvm == 2) hipLaunchKernelGGL(k_attn_scores_kv<2>, dim3(gx, gy), dim3(kWG), smem, st, a);
+    else hipLaunchKernelGGL(k_attn_scores, dim3(gx, gy), dim3(kWG), smem, st, a);
+}
+
 void launch_one(const Launch& L, q3_engine* e) {
     if (L.is_attn) {
-        if (L.attn_kind == 1) hipLaunchKernelGGL(k_attn_scores, dim3(L.grid, L.grid_y), dim3(kWG), L.smem, e->stream, L.aa);
+        if (L.attn_kind == 1) launch_attn_scores(L.aa, L.scores_kvm, L.grid, L.grid_y, L.smem, e->stream);
         else if (L.attn_kind == 2) launch_attn_out(L.aa, L.grid, L.grid_y, L.smem, e->stream);
         else if (L.attn_kind == 3) {
             if (L.aa.hd == 128) hipLaunchKernelGGL(k_attn_short<128>, dim3(L.grid), dim3(kWG), 0, e->stream, L.aa);
@@ -695,12 +724,16 @@ int q3_engine::build_plan() {
         if (!L0.is_attn) { plan_long.push_back(L0); continue; }
         Launch A = L0, B = L0;
         A.attn_kind = 1;
-        A.aa.stamps = nullptr;            // developer timeline of the long plan: k_attn_out's
+        A.aa.stamps = nullptr;            // developer timeline of the long plan: k_attn_out's (Q3_STAMP_SCORES=1: k_attn_scores')
+        if (env_int("Q3_STAMP_SCORES", 0)) { A.aa.stamps = L0.aa.stamps; B.aa.stamps = nullptr; }
         A.aa.att_global = d_att;
         A.aa.att_stride = att_stride;
         A.aa.q_out = nullptr;
-        A.grid_y = (unsigned)((S + attn_tch(hd) - 1) / attn_tch(hd));
-        A.smem = attn_scores_smem_bytes(hd);
+        const ScoresShape ss = scores_shape(hd, A.aa.n_heads, A.aa.n_kv_heads, S);
+        A.scores_kvm = ss.kvm;
+        A.grid = ss.gx;
+        A.grid_y = ss.gy;
+        A.smem = ss.smem;
         B.attn_kind = 2;
         B.aa.att_global = d_att;
         B.aa.att_priv = d_att_priv;
@@ -708,7 +741,7 @@ int q3_engine::build_plan() {
         B.grid_y = (unsigned)nsl;
         B.aa.slice_w = slice_w;
         B.smem = attn_out_smem_bytes(hd, S, slice_w);
-        if ((rc = set_max_smem((const void*)k_attn_scores, A.smem))) return rc;
+        if ((rc = set_attn_scores_smem(ss))) return rc;
         if ((rc = set_attn_out_smem(B.smem))) return rc;
         plan_long.push_back(A);
         plan_long.push_back(B);
@@ -1279,11 +1312,11 @@ int q3_op_attention(float* xb, float* q, float* key_cache_layer, const float* va
         a.att_stride = att_stride;
         a.att_priv = dpriv.as<float>();
         a.q_out = dqout.as<float>();
-        const size_t sm1 = attn_scores_smem_bytes((int)head_dim), sm2 = attn_out_smem_bytes((int)head_dim, (int)seq_len, slice_w);
+        const size_t sm2 = attn_out_smem_bytes((int)head_dim, (int)seq_len, slice_w);
         a.slice_w = slice_w;
-        if ((rc = set_max_smem((const void*)k_attn_scores, sm1)) || (rc = set_attn_out_smem(sm2))) return rc;
-        const unsigned nchunk = (unsigned)((seq_len + attn_tch((int)head_dim) - 1) / attn_tch((int)head_dim));
-        hipLaunchKernelGGL(k_attn_scores, dim3((unsigned)n_heads, nchunk), dim3(kWG), sm1, 0, a);
+        const ScoresShape ss = scores_shape((int)head_dim, (int)n_heads, (int)n_kv_heads, (int)seq_len);
+        if ((rc = set_attn_scores_smem(ss)) || (rc = set_attn_out_smem(sm2))) return rc;
+        launch_attn_scores(a, ss.kvm, ss.gx, ss.gy, ss.smem, 0);
         launch_attn_out(a, (unsigned)n_heads, (unsigned)nsl, sm2, 0);
         if ((rc = op_end())) return rc;
         HIP_TRY(hipMemcpy(dq.p, dqout.p, 4 * ahd, hipMemcpyDeviceToDevice));

@@ -1740,6 +1740,7 @@ __host__ __device__ inline size_t attn_out_smem_bytes(int hd, int seq_len, int w
 
 __global__ __launch_bounds__(kWG) void k_attn_scores(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    ATT_STAMP(0);
     const int hd = a.hd, tch = attn_tch(hd), kld = hd + kKPad;
     float* q_s = (float*)smem_raw;
     float* k_s = q_s + hd;
@@ -1773,12 +1774,15 @@ __global__ __launch_bounds__(kWG) void k_attn_scores(const AttnArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     stage_issue(sk, kbase, kvd, t0, cnt, hd);
     __builtin_amdgcn_sched_barrier(0);
+    ATT_STAMP(1);
     if (tid < hd) { raw[tid] = rq; raw[hd + tid] = rk; }
     __syncthreads();
     if (wave == 0) wave_norm_rope(q_s, raw, sq, rr, hd, a.strict);
     else if (wave == 1 && has_pos) wave_norm_rope(k_s, raw + hd, sq + hd, rr, hd, a.strict);
+    ATT_STAMP(2);
     stage_commit(sk, kbuf, kld, t0, cnt, hd, pos);
     __syncthreads();
+    ATT_STAMP(3);
     if (has_pos) {
         for (int i = tid; i < hd; i += kWG) kbuf[(pos - t0) * kld + i] = k_s[i];
         if (h % kv_mul == 0) {
@@ -1789,6 +1793,7 @@ __global__ __launch_bounds__(kWG) void k_attn_scores(const AttnArgs a) {
     if (a.q_out != nullptr && c == 0)
         for (int i = tid; i < hd; i += kWG) a.q_out[(size_t)h * hd + i] = q_s[i];
     __syncthreads();
+    ATT_STAMP(4);
     const float scale = 1.0f / sqrtf((float)hd);
     if (a.strict) {
         for (int t = tid; t < cnt; t += kWG) {
@@ -1836,6 +1841,137 @@ __global__ __launch_bounds__(kWG) void k_attn_scores(const AttnArgs a) {
             if (t < cnt && li == 0) att[t0 + t] = p * scale;
         }
     }
+    ATT_STAMP(5);
+    ATT_STAMP(6);
+}
+
+// k_attn_scores with the staged K chunk shared by the KVM_T query heads of one kv head (head_dim 128, KVM_T 2 or 4):
+// grid (kv heads, chunks of 64 * 4/KVM_T timesteps).  k_attn_scores stages the same chunk once per QUERY head, so at a
+// position in the thousands every CU pulls KVM_T times the cache through L2 and the staging burst -- not the dot chains
+// -- sets the launch time.  Here wave w owns query head w % KVM_T and timesteps (w / KVM_T) * 64 + lane: one sequential
+// 128-term dot per lane (attention.rs:96-104 order), q broadcast from LDS, K rows read lane-per-row from the padded tile.
+constexpr int kSgHd = 128;
+template <int KVM_T> __host__ __device__ constexpr int sg_tch() { return 64 * (kWaves / KVM_T); }
+template <int KVM_T> __host__ __device__ constexpr size_t attn_scores_kv_smem_bytes() {
+    return 4 * ((size_t)kSgHd * (KVM_T + 1 + (KVM_T + 1) + kWaves) + (size_t)sg_tch<KVM_T>() * (kSgHd + kKPad));
+}
+template <int KVM_T>
+__global__ __launch_bounds__(kWG) void k_attn_scores_kv(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    ATT_STAMP(0);
+    constexpr int hd = kSgHd, kld = hd + kKPad, TCH = sg_tch<KVM_T>();
+    constexpr int NS = TCH * (hd / 4) / kWG;           // float4 staged per thread (8 or 16)
+    constexpr int rps = kWG / (hd / 4);                // rows covered by one slot of the whole workgroup
+    float* q_s = (float*)smem_raw;                     // [KVM_T][hd]
+    float* k_s = q_s + KVM_T * hd;                     // [hd]
+    float* raw = k_s + hd;                             // [KVM_T + 1][hd]: raw q per head | raw k
+    float* sq = raw + (KVM_T + 1) * hd;                // [kWaves][hd]
+    float* kbuf = sq + kWaves * hd;                    // [TCH][kld]
+
+    const int kvh = blockIdx.x, c = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t kvd = (size_t)a.n_kv_heads * hd;
+    const int pos = __builtin_amdgcn_readfirstlane(a.pos_override >= 0 ? a.pos_override : a.st->pos);
+    const int np = pos + 1;
+    const int t0 = c * TCH;
+    if (t0 >= np) return;
+    const int cnt = min(TCH, np - t0);
+    const bool has_pos = pos < t0 + cnt;
+    const float* cs = a.rope + (size_t)pos * hd;
+    // the wave that normalises the new K row: the first one without a query head, or wave 0 after its own head
+    constexpr int kwave = KVM_T < kWaves ? KVM_T : 0;
+
+    float rv[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int idx = tid + u * kWG;                 // (KVM_T + 1) * 128 <= 640 values: raw q of each head, then raw k
+        if (idx < KVM_T * hd) rv[u] = a.q[(size_t)kvh * KVM_T * hd + idx];
+        else if (idx < (KVM_T + 1) * hd && has_pos) rv[u] = a.k_raw[(size_t)kvh * hd + idx - KVM_T * hd];
+    }
+    float rv2 = 0.f;
+    if (KVM_T == 4 && tid < hd && has_pos) rv2 = a.k_raw[(size_t)kvh * hd + tid];
+    RopeRegs rr, rrk;
+    rope_regs_load(rr, wave < KVM_T ? a.q_norm_w : a.k_norm_w, cs, hd);
+    rrk = rr;
+    if (KVM_T == kWaves && wave == kwave && has_pos) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = min(lane + 64 * u, hd / 2 - 1);
+            rrk.w_lo[u] = a.k_norm_w[i];
+            rrk.w_hi[u] = a.k_norm_w[i + hd / 2];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    v4f sv[NS];
+    {
+        const int r0 = tid / (hd / 4), c4 = tid % (hd / 4);
+        const float* p = a.key_cache + (size_t)kvh * hd + (size_t)(t0 + r0) * kvd + 4 * c4;
+        const size_t stride = (size_t)rps * kvd;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const bool ok = r0 + u * rps < cnt;         // unconditional loads (see stage_issue)
+            sv[u] = *(const v4f*)(ok ? p + u * stride : p);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    ATT_STAMP(1);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int idx = tid + u * kWG;
+        if (KVM_T == 4) { if (u == 0 || idx < KVM_T * hd) raw[idx] = rv[u]; }
+        else if (idx < (KVM_T + 1) * hd) raw[idx] = rv[u];
+    }
+    if (KVM_T == 4 && tid < hd) raw[KVM_T * hd + tid] = rv2;
+    __syncthreads();
+    if (wave < KVM_T) wave_norm_rope(q_s + wave * hd, raw + wave * hd, sq + wave * hd, rr, hd, a.strict);
+    if (wave == kwave && has_pos) wave_norm_rope(k_s, raw + KVM_T * hd, sq + wave * hd, rrk, hd, a.strict);
+    ATT_STAMP(2);
+    {
+        const int r0 = tid / (hd / 4), c4 = tid % (hd / 4);
+        float* p = kbuf + r0 * kld + 4 * c4;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int r = r0 + u * rps;
+            if (r < cnt && t0 + r != pos) *(v4f*)(p + u * rps * kld) = sv[u];
+        }
+    }
+    __syncthreads();
+    ATT_STAMP(3);
+    if (has_pos) {
+        if (tid < hd) {
+            const float kv = k_s[tid];
+            kbuf[(pos - t0) * kld + tid] = kv;
+            a.key_cache[(size_t)pos * kvd + (size_t)kvh * hd + tid] = kv;
+        }
+    }
+    if (a.q_out != nullptr && c == 0)
+        for (int i = tid; i < KVM_T * hd; i += kWG) a.q_out[(size_t)kvh * KVM_T * hd + i] = q_s[i];
+    if (has_pos) __syncthreads();
+    ATT_STAMP(4);
+    {
+        const int j = wave % KVM_T, t = (wave / KVM_T) * 64 + lane;
+        if (t < cnt) {
+            const v4f* k4 = (const v4f*)(kbuf + t * kld);
+            const v4f* q4 = (const v4f*)(q_s + j * hd);
+            float dot = -0.0f;
+#pragma unroll
+            for (int i = 0; i < hd / 4; i += 16) {
+                v4f kk[16], qq[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { kk[u] = k4[i + u]; qq[u] = q4[i + u]; }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    float p = qq[u].x * kk[u].x; dot = dot + p;
+                    p = qq[u].y * kk[u].y; dot = dot + p;
+                    p = qq[u].z * kk[u].z; dot = dot + p;
+                    p = qq[u].w * kk[u].w; dot = dot + p;
+                }
+            }
+            a.att_global[(size_t)(kvh * KVM_T + j) * a.att_stride + t0 + t] = dot * (1.0f / sqrtf((float)hd));
+        }
+    }
+    ATT_STAMP(5);
+    ATT_STAMP(6);
 }
 
 // W_T: the slice width as a compile-time constant (8 / 16 / 32 cover every listed model; 0 = read a.slice_w): the staging

@@ -289,6 +289,36 @@ def test_0p6b_dims_every_position_to_the_split_vs_oracle(q3, oracle):
             assert_biteq(np.array(t.forward(5, p), copy=True), om.forward(5, p), f"forward(5,{p})")
 
 
+def test_4b_dims_long_context_split_vs_oracle(q3, oracle):
+    """BASELINE config 3's layer dimensions (dim 2560, 32 heads over 8 kv heads, head_dim 128) with 2 layers, past the
+    split point: the scores kernel that stages each K chunk once for the four query heads of a kv head runs with full
+    64-timestep chunks and a ragged last one that holds the new row.  Tokens, logits and both caches vs the oracle."""
+    ck = q3.checkpoint
+    name = "qwen3-4b-dims-l2"
+    sh = ck.SHAPES[name]
+    path = os.path.join(os.environ.get("Q3_CKPT_DIR", "/tmp"), f"q3_{name}.bin")
+    ck.ensure_synthetic_checkpoint(path, sh, seed=78)
+    n, ctx = 262, 336
+    om = oracle.OracleModel(path, ctx)
+    toks = [int(v) for v in np.random.default_rng(4).integers(0, sh.vocab_size, size=n)]
+    for p in range(n):
+        lg = om.forward(toks[p], p)
+    nxt = oracle.sample_argmax(lg)
+    with q3.TransformerBuilder(path).with_ctx_length(ctx).build() as t:
+        assert t.prefill(toks, 0) == nxt
+        tk = nxt
+        for p in range(n, n + 62):                          # crosses the 320-timestep chunk boundary
+            want = om.forward(tk, p)
+            assert_biteq(np.array(t.forward(tk, p), copy=True), want, f"forward({tk},{p})")
+            tk = oracle.sample_argmax(want)
+        n = n + 62
+        kvd = sh.n_kv_heads * sh.head_dim
+        ok, ov = om.kv_cache()
+        for layer in range(sh.n_layers):
+            assert_biteq(t.read_state("key", layer * ctx * kvd, n * kvd), ok.reshape(sh.n_layers, -1)[layer][:n * kvd], "key cache")
+            assert_biteq(t.read_state("value", layer * ctx * kvd, n * kvd), ov.reshape(sh.n_layers, -1)[layer][:n * kvd], "value cache")
+
+
 def test_long_context_split_attention_vs_oracle(q3, oracle, tmp_ckpt_dir):
     """pos >= 256 switches the engine to the long-context launch plan (scores over heads x T-chunks, softmax + V over
     heads x element slices).  Logits stay bit-identical across the switch, at chunk boundaries and deep into the
