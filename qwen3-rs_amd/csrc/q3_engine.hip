@@ -242,18 +242,29 @@ struct q3_engine {
 
 namespace {
 
-void launch_attn_out(const AttnArgs& aa, unsigned gx, unsigned gy, size_t smem, hipStream_t st) {
+template <bool P_LDS>
+void launch_attn_out_t(const AttnArgs& aa, unsigned gx, unsigned gy, size_t smem, hipStream_t st) {
     switch (aa.slice_w) {
-        case 8: hipLaunchKernelGGL(k_attn_out<8>, dim3(gx, gy), dim3(kWG), smem, st, aa); break;
-        case 16: hipLaunchKernelGGL(k_attn_out<16>, dim3(gx, gy), dim3(kWG), smem, st, aa); break;
-        case 32: hipLaunchKernelGGL(k_attn_out<32>, dim3(gx, gy), dim3(kWG), smem, st, aa); break;
-        default: hipLaunchKernelGGL(k_attn_out<0>, dim3(gx, gy), dim3(kWG), smem, st, aa); break;
+        case 8: hipLaunchKernelGGL((k_attn_out<8, P_LDS>), dim3(gx, gy), dim3(kWG), smem, st, aa); break;
+        case 16: hipLaunchKernelGGL((k_attn_out<16, P_LDS>), dim3(gx, gy), dim3(kWG), smem, st, aa); break;
+        case 32: hipLaunchKernelGGL((k_attn_out<32, P_LDS>), dim3(gx, gy), dim3(kWG), smem, st, aa); break;
+        default: hipLaunchKernelGGL((k_attn_out<0, P_LDS>), dim3(gx, gy), dim3(kWG), smem, st, aa); break;
     }
+}
+void launch_attn_out(const AttnArgs& aa, unsigned gx, unsigned gy, size_t smem, hipStream_t st) {
+    if (attn_out_p_in_lds(aa.seq_len)) launch_attn_out_t<true>(aa, gx, gy, smem, st);
+    else launch_attn_out_t<false>(aa, gx, gy, smem, st);
+}
+template <bool P_LDS>
+int set_attn_out_smem_t(size_t bytes) {
+    int rc;
+    if ((rc = set_max_smem((const void*)k_attn_out<8, P_LDS>, bytes)) || (rc = set_max_smem((const void*)k_attn_out<16, P_LDS>, bytes)) ||
+        (rc = set_max_smem((const void*)k_attn_out<32, P_LDS>, bytes)) || (rc = set_max_smem((const void*)k_attn_out<0, P_LDS>, bytes))) return rc;
+    return Q3_OK;
 }
 int set_attn_out_smem(size_t bytes) {
     int rc;
-    if ((rc = set_max_smem((const void*)k_attn_out<8>, bytes)) || (rc = set_max_smem((const void*)k_attn_out<16>, bytes)) ||
-        (rc = set_max_smem((const void*)k_attn_out<32>, bytes)) || (rc = set_max_smem((const void*)k_attn_out<0>, bytes))) return rc;
+    if ((rc = set_attn_out_smem_t<true>(bytes)) || (rc = set_attn_out_smem_t<false>(bytes))) return rc;
     return Q3_OK;
 }
 

@@ -1733,6 +1733,7 @@ constexpr int kPLds = 8192;    // probability rows up to this length live in LDS
 __host__ __device__ inline size_t attn_scores_smem_bytes(int hd) {
     return 4 * ((size_t)hd * 6 + 64 + (size_t)attn_tch(hd) * (hd + kKPad));
 }
+__host__ __device__ inline bool attn_out_p_in_lds(int seq_len) { return ((seq_len + 255) & ~255) <= kPLds; }
 __host__ __device__ inline size_t attn_out_smem_bytes(int hd, int seq_len, int w) {
     const int pl = ((seq_len + 255) & ~255) <= kPLds ? ((seq_len + 255) & ~255) : 0;
     return 4 * (2 * (size_t)(kVChunk + kVPad) * w + 2 * kVChunk + 64 + (size_t)kWaves * w + (size_t)pl) + 32 * 8;   // V / p chunk tiles double buffered; exp2 table
@@ -1977,7 +1978,10 @@ __global__ __launch_bounds__(kWG) void k_attn_scores_kv(const AttnArgs a) {
 // W_T: the slice width as a compile-time constant (8 / 16 / 32 cover every listed model; 0 = read a.slice_w): the staging
 // pass count and every index derived from it fold, and the per-slot `if (u < npass)` branches disappear -- each of them
 // put its load in a basic block of its own, which makes hipcc throttle the burst with conservative vmcnt waits.
-template <int W_T>
+// P_LDS: the probability row lives in LDS (contexts up to kPLds positions) -- a compile-time fact, because a pointer that
+// is LDS or global at run time makes every access a FLAT instruction (slower, and it ties the LDS and vector-memory wait
+// counters together).
+template <int W_T, bool P_LDS>
 __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     ATT_STAMP(0);
@@ -1998,8 +2002,10 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
     const int npad = (np + 255) & ~255;                  // whole 64 x (npad/64) blocks for the exact sum
     const float* src = a.att_global + (size_t)h * a.att_stride;
     const int npad_max = (a.seq_len + 255) & ~255;
-    const bool p_in_lds = npad_max <= kPLds;
-    float* p = p_in_lds ? p_lds : a.att_priv + ((size_t)h * nsl + sl) * a.att_stride;
+    constexpr bool p_in_lds = P_LDS;                     // (host: attn_out_p_in_lds(seq_len))
+    float* p;
+    if constexpr (P_LDS) p = p_lds; else p = a.att_priv + ((size_t)h * nsl + sl) * a.att_stride;
+    float* dummy = opart;                                // LDS word nobody reads before the epilogue: target of masked-off stores
     const float* vbase = a.value_cache + (size_t)kvh * hd + (size_t)sl * w;
 
     const int w4s = __builtin_ctz(w >> 2);               // float4 per slice row = 1 << w4s
@@ -2031,15 +2037,14 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
         }
     };
     constexpr int K = kVChunk;
-    v_issue(vra, 0);                                     // the first two V chunks travel under the softmax
-    if (K < np) v_issue(vrb, K);
 
     // exp2 table of q3_expf staged in LDS (a dependent global load per exp otherwise)
     unsigned long long* etab = (unsigned long long*)(p_lds + (p_in_lds ? npad_max : 0));
     if (tid < 32) etab[tid] = kExp2Tab[tid];
 
-    // ---- softmax (layers.rs:495-506) into this workgroup's private probability row.  Scores are pulled 8 per thread at
-    // a time (independent loads in flight together), twice: the second pass hits L1.
+    // ---- softmax (layers.rs:495-506) into this workgroup's private probability row.  The scores are on the critical path
+    // and go out first (16 independent loads per thread: one trip covers 4096 positions and the values then stay in
+    // registers for the exp pass); the first two V chunks follow and travel under the softmax.
     // The exact sum wants power-of-two blocks of <= 64 terms in registers, one lane each, read conflict-free: besides the
     // contiguous row p[] a copy padded by 4 floats per block goes into the (still unused) first V tile.
     int bl = 4;
@@ -2048,29 +2053,75 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
     const int blsh = __builtin_ctz(bl);
     float* esc = vbuf0;                                  // (np/bl) x (bl + 4) floats <= 4352 <= one V tile of any slice width
     float m = -__builtin_inff();
-    for (int t0 = 0; t0 < np; t0 += 16 * kWG) {          // 16 independent loads per thread in flight (np <= 4096: one trip)
-        float sv[16];
+    const bool one_trip = np <= 16 * kWG;
+    float sv[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) sv[u] = src[min(t0 + u * kWG + tid, np - 1)];
+    for (int u = 0; u < 16; ++u) sv[u] = src[min(u * kWG + tid, np - 1)];
+    __builtin_amdgcn_sched_barrier(0);
+    v_issue(vra, 0);
+    if (K < np) v_issue(vrb, K);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) m = fmaxf(m, sv[u]);
+    for (int u = 0; u < 16; ++u) m = fmaxf(m, sv[u]);
+    for (int t0 = 16 * kWG; t0 < np; t0 += 16 * kWG) {   // rows beyond 4096 positions
+        float s2[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s2[u] = src[min(t0 + u * kWG + tid, np - 1)];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) m = fmaxf(m, s2[u]);
     }
     m = block_max(m, red);                               // (its barriers also publish etab)
     ATT_STAMP(1);
     float part = 0.0f;
-    for (int t0 = 0; t0 < npad; t0 += 8 * kWG) {
-        float sv[8];
+    const int nblk_terms = ((np + bl - 1) >> blsh) << blsh;
+    if (one_trip) {
+        // exps in groups of four (their f64 chains interleave; a guard around each one would serialise them), whole groups
+        // past the padded row skipped
 #pragma unroll
-        for (int u = 0; u < 8; ++u) sv[u] = src[min(t0 + u * kWG + tid, np - 1)];
+        for (int g = 0; g < 4; ++g) {
+            if (g * 4 * kWG < npad) {
+                float ev[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int t = t0 + u * kWG + tid;
-            if (t < npad) {
-                float e = q3_expf_t(t < np ? sv[u] - m : 0.0f, etab);
-                e = t < np ? e : 0.0f;                   // +0.0 padding leaves every partial sum unchanged
-                part = part + e;
-                p[t] = e;
-                if (padded && t < (((np + bl - 1) >> blsh) << blsh)) esc[(t >> blsh) * (bl + kSpecPad) + (t & (bl - 1))] = e;
+                for (int u = 0; u < 4; ++u) {
+                    const int t = (g * 4 + u) * kWG + tid;
+                    const float e = q3_expf_t(t < np ? sv[g * 4 + u] - m : 0.0f, etab);
+                    ev[u] = t < np ? e : 0.0f;           // +0.0 padding leaves every partial sum unchanged
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = (g * 4 + u) * kWG + tid;
+                    part = part + ev[u];
+                    if constexpr (P_LDS) {
+                        // masked-off stores go to a dummy word instead of sitting behind a branch: LLVM sinks the whole exp
+                        // into a guarded block otherwise and the four chains no longer interleave
+                        *(t < npad ? p + t : dummy) = ev[u];
+                        *((padded && t < nblk_terms) ? esc + (t >> blsh) * (bl + kSpecPad) + (t & (bl - 1)) : dummy) = ev[u];
+                    } else if (t < npad) {
+                        p[t] = ev[u];
+                        if (padded && t < nblk_terms) esc[(t >> blsh) * (bl + kSpecPad) + (t & (bl - 1))] = ev[u];
+                    }
+                }
+            }
+        }
+    } else {
+        for (int t0 = 0; t0 < npad; t0 += 4 * kWG) {
+            float s2[4], ev[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s2[u] = src[min(t0 + u * kWG + tid, np - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + u * kWG + tid;
+                const float e = q3_expf_t(t < np ? s2[u] - m : 0.0f, etab);
+                ev[u] = t < np ? e : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + u * kWG + tid;
+                if (t < npad) {
+                    part = part + ev[u];
+                    p[t] = ev[u];
+                    if (padded && t < nblk_terms) esc[(t >> blsh) * (bl + kSpecPad) + (t & (bl - 1))] = ev[u];
+                }
             }
         }
     }
@@ -2083,9 +2134,13 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
     } else sum = block_sum_fast(part, red);
     ATT_STAMP(3);
     const float inv = 1.0f / sum;
-    __syncthreads();
-    for (int t = tid; t < np; t += kWG) p[t] = p[t] * inv;
-    __syncthreads();
+    __syncthreads();                                     // (the exact sum read its blocks out of the first V tile)
+    // reference order: p stays unnormalised, the staging threads form (e * inv) * v themselves (same two roundings as
+    // normalising the row first, layers.rs:503-505 then 406-417) -- one pass over the row and one barrier less
+    if (!a.strict) {
+        for (int t = tid; t < np; t += kWG) p[t] = p[t] * inv;
+        __syncthreads();
+    }
     ATT_STAMP(4);
 
     // ---- out[e] = sum_t p[t] * V[t][e]  (layers.rs:406-417), V slices staged kVChunk timesteps at a time
@@ -2100,20 +2155,26 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
             if (a.strict) {
                 // transposed, rows past the context zero-filled: the accumulation below runs in whole float4 steps and
                 // p = +0.0 there, so the padded terms add +0.0 (o + 0.0 == o: o is never -0.0, it starts from +0.0)
+                // The tile holds the PRODUCTS p[t] * v[t][e]: the chain lanes then issue one LDS read and four adds per four
+                // timesteps, which keeps the issue rate under the 10-cycle dependent add (with the multiplies in the chain lane
+                // the fold ran at ~21 cycles per timestep).
                 if (u < npass && r < kVChunk) {
                     const bool live = c0 + r < np;
+                    const float pn = p[min(c0 + r, np - 1)] * inv;
                     const v4f vv = R.v[u];
                     float* dst = vbuf + (4 * c4) * VLD + r;
-                    dst[0] = live ? vv.x : 0.0f;
-                    dst[VLD] = live ? vv.y : 0.0f;
-                    dst[2 * VLD] = live ? vv.z : 0.0f;
-                    dst[3 * VLD] = live ? vv.w : 0.0f;
+                    const float x0 = pn * vv.x, x1 = pn * vv.y, x2 = pn * vv.z, x3 = pn * vv.w;
+                    dst[0] = live ? x0 : 0.0f;
+                    dst[VLD] = live ? x1 : 0.0f;
+                    dst[2 * VLD] = live ? x2 : 0.0f;
+                    dst[3 * VLD] = live ? x3 : 0.0f;
                 }
             } else if (u < npass && r < kVChunk && c0 + r < np) {
                 *(v4f*)(vbuf + r * w + 4 * c4) = R.v[u];
             }
         }
-        for (int t = sid; t < kVChunk; t += nst) pbuf[t] = (c0 + t < np) ? p[c0 + t] : 0.0f;
+        if (!a.strict)
+            for (int t = sid; t < kVChunk; t += nst) pbuf[t] = (c0 + t < np) ? p[c0 + t] : 0.0f;
     };
     // fold chunk c0 out of LDS tile `buf` (committed one barrier earlier)
     auto fold = [&](int c0, int buf) {
@@ -2122,31 +2183,30 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
         const float* pbuf = pbuf0 + buf * kVChunk;
         if (a.strict) {
             if (tid < w) {
-                // one sequential chain per output element (layers.rs:406-417); operands arrive as float4 (4 timesteps)
-                // and the next 16 timesteps are in flight while the current 16 are folded
+                // one sequential chain per output element (layers.rs:406-417): the products of 4 timesteps arrive as one
+                // float4 and the next 16 timesteps are in flight while the current 16 are added
                 const v4f* vr = (const v4f*)(vbuf + tid * VLD);
-                const v4f* pr4 = (const v4f*)pbuf;
                 const int nq8 = ((cnt + 31) >> 5) << 3;          // float4 steps, whole blocks of 8 (zero padded, <= kVChunk/4)
-                auto fold4 = [&](v4f pv, v4f vv) {
-                    float t0 = pv.x * vv.x; o_s = o_s + t0;
-                    t0 = pv.y * vv.y; o_s = o_s + t0;
-                    t0 = pv.z * vv.z; o_s = o_s + t0;
-                    t0 = pv.w * vv.w; o_s = o_s + t0;
+                auto fold4 = [&](v4f x) {
+                    o_s = o_s + x.x;
+                    o_s = o_s + x.y;
+                    o_s = o_s + x.z;
+                    o_s = o_s + x.w;
                 };
-                v4f av[4], ap[4], bv[4], bp[4];
+                v4f av[4], bv[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { av[u] = vr[u]; ap[u] = pr4[u]; }
+                for (int u = 0; u < 4; ++u) av[u] = vr[u];
                 for (int q = 0; q < nq8; q += 8) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) { bv[u] = vr[q + 4 + u]; bp[u] = pr4[q + 4 + u]; }
+                    for (int u = 0; u < 4; ++u) bv[u] = vr[q + 4 + u];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) fold4(ap[u], av[u]);
+                    for (int u = 0; u < 4; ++u) fold4(av[u]);
                     if (q + 8 < nq8) {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) { av[u] = vr[q + 8 + u]; ap[u] = pr4[q + 8 + u]; }
+                        for (int u = 0; u < 4; ++u) av[u] = vr[q + 8 + u];
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) fold4(bp[u], bv[u]);
+                    for (int u = 0; u < 4; ++u) fold4(bv[u]);
                 }
             }
         } else {
