@@ -12,3 +12,6 @@ with q3.TransformerBuilder(path).with_ctx_length(4096).build() as t:
     t.generate_greedy(5, pos, 4)
     t0 = time.perf_counter(); t.generate_greedy(5, pos, steps); dt = time.perf_counter() - t0
     print(f"{name} pos {pos}: {dt/steps*1e6:.1f} us/token")
+    if os.environ.get("Q3_PROFILE_FAMILIES", "1") != "0":
+        for fam, ms, n in t.profile(5, pos, 8):
+            print(f"  {fam:8s} {ms/8*1e3:8.1f} us/token  {n//8:4d} launches  {ms/n*1e3:6.2f} us each")
