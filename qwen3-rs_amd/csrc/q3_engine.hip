@@ -245,10 +245,10 @@ namespace {
 template <bool P_LDS>
 void launch_attn_out_t(const AttnArgs& aa, unsigned gx, unsigned gy, size_t smem, hipStream_t st) {
     switch (aa.slice_w) {
-        case 8: hipLaunchKernelGGL((k_attn_out<8, P_LDS>), dim3(gx, gy), dim3(kWG), smem, st, aa); break;
-        case 16: hipLaunchKernelGGL((k_attn_out<16, P_LDS>), dim3(gx, gy), dim3(kWG), smem, st, aa); break;
-        case 32: hipLaunchKernelGGL((k_attn_out<32, P_LDS>), dim3(gx, gy), dim3(kWG), smem, st, aa); break;
-        default: hipLaunchKernelGGL((k_attn_out<0, P_LDS>), dim3(gx, gy), dim3(kWG), smem, st, aa); break;
+        case 8: hipLaunchKernelGGL((k_attn_out<8, P_LDS>), dim3(gx, gy), dim3(kAoThreads), smem, st, aa); break;
+        case 16: hipLaunchKernelGGL((k_attn_out<16, P_LDS>), dim3(gx, gy), dim3(kAoThreads), smem, st, aa); break;
+        case 32: hipLaunchKernelGGL((k_attn_out<32, P_LDS>), dim3(gx, gy), dim3(kAoThreads), smem, st, aa); break;
+        default: hipLaunchKernelGGL((k_attn_out<0, P_LDS>), dim3(gx, gy), dim3(kAoThreads), smem, st, aa); break;
     }
 }
 void launch_attn_out(const AttnArgs& aa, unsigned gx, unsigned gy, size_t smem, hipStream_t st) {

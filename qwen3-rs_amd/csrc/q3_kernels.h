@@ -1736,7 +1736,7 @@ __host__ __device__ inline size_t attn_scores_smem_bytes(int hd) {
 __host__ __device__ inline bool attn_out_p_in_lds(int seq_len) { return ((seq_len + 255) & ~255) <= kPLds; }
 __host__ __device__ inline size_t attn_out_smem_bytes(int hd, int seq_len, int w) {
     const int pl = ((seq_len + 255) & ~255) <= kPLds ? ((seq_len + 255) & ~255) : 0;
-    return 4 * (2 * (size_t)(kVChunk + kVPad) * w + 2 * kVChunk + 64 + (size_t)kWaves * w + (size_t)pl) + 32 * 8;   // V / p chunk tiles double buffered; exp2 table
+    return 4 * (2 * (size_t)(kVChunk + kVPad) * w + 2 * kVChunk + 64 + (size_t)16 * w + (size_t)pl) + 32 * 8;   // V / p chunk tiles double buffered; [kAoWaves][w] partials; exp2 table
 }
 
 __global__ __launch_bounds__(kWG) void k_attn_scores(const AttnArgs a) {
@@ -1978,11 +1978,36 @@ __global__ __launch_bounds__(kWG) void k_attn_scores_kv(const AttnArgs a) {
 // W_T: the slice width as a compile-time constant (8 / 16 / 32 cover every listed model; 0 = read a.slice_w): the staging
 // pass count and every index derived from it fold, and the per-slot `if (u < npass)` branches disappear -- each of them
 // put its load in a basic block of its own, which makes hipcc throttle the burst with conservative vmcnt waits.
+// 1024 threads per workgroup: one workgroup per CU either way (256 of them), and the softmax in front of the chain -- the
+// score loads and above all the exps, ~70 instructions each on the f64 pipe -- is spread over 16 waves instead of 4
+constexpr int kAoThreads = 1024, kAoWaves = kAoThreads / 64;
+constexpr int kAoSv = 4096 / kAoThreads;              // scores per thread kept in registers (rows up to 4096 positions)
+template <int NW> __device__ __forceinline__ float block_max_n(float v, float* red) {
+    v = group_max_f32(v, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t = fmaxf(t, red[w]);
+    __syncthreads();
+    return t;
+}
+template <int NW> __device__ __forceinline__ float block_sum_fast_n(float v, float* red) {
+    v = group_sum_f32(v, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t += red[w];
+    __syncthreads();
+    return t;
+}
 // P_LDS: the probability row lives in LDS (contexts up to kPLds positions) -- a compile-time fact, because a pointer that
 // is LDS or global at run time makes every access a FLAT instruction (slower, and it ties the LDS and vector-memory wait
 // counters together).
 template <int W_T, bool P_LDS>
-__global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
+// (developer timeline, Q3_DEV builds: 1 loads issued, 2 scores in registers, 3 max, 4 exps written, 5 exact sum, 6 end)
+__global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     ATT_STAMP(0);
     const int hd = a.hd;
@@ -1990,16 +2015,13 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
     float* vbuf0 = (float*)smem_raw;                     // 2 x [kVChunk][w]  (reference order: [w][kVChunk + kVPad])
     float* pbuf0 = vbuf0 + 2 * (kVChunk + kVPad) * w;    // 2 x [kVChunk]
     float* red = pbuf0 + 2 * kVChunk;                    // [64]
-    float* opart = red + 64;                             // [kWaves][w]
-    float* p_lds = opart + kWaves * w;                   // [npad] when the row fits (see attn_out_smem_bytes)
+    float* opart = red + 64;                             // [kAoWaves][w]
+    float* p_lds = opart + kAoWaves * w;                   // [npad] when the row fits (see attn_out_smem_bytes)
 
     const int h = blockIdx.x, sl = blockIdx.y, nsl = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kv_mul = a.n_heads / a.n_kv_heads, kvh = h / kv_mul;
     const size_t kvd = (size_t)a.n_kv_heads * hd;
-    const int pos = __builtin_amdgcn_readfirstlane(a.pos_override >= 0 ? a.pos_override : a.st->pos);   // wave-uniform -> SGPR
-    const int np = pos + 1;
-    const int npad = (np + 255) & ~255;                  // whole 64 x (npad/64) blocks for the exact sum
     const float* src = a.att_global + (size_t)h * a.att_stride;
     const int npad_max = (a.seq_len + 255) & ~255;
     constexpr bool p_in_lds = P_LDS;                     // (host: attn_out_p_in_lds(seq_len))
@@ -2011,12 +2033,12 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
     const int w4s = __builtin_ctz(w >> 2);               // float4 per slice row = 1 << w4s
     // Reference-order mode with slices of 8 / 16 elements: the chain lanes live in wave 0, so wave 0 only folds and the
     // other three waves do all the staging (a chunk still fits their 8 register slots); otherwise every thread stages.
-    const bool w0_folds = (W_T == 8 || W_T == 16) && a.strict;
+    constexpr bool w0_folds = (W_T == 8 || W_T == 16);   // (in both modes, so that the staging shape is a compile-time fact)
     const bool stager = !w0_folds || tid >= 64;          // wave-uniform
-    const int nst = w0_folds ? kWG - 64 : kWG;           // staging threads
+    constexpr int nst = w0_folds ? kAoThreads - 64 : kAoThreads;   // staging threads
     const int sid = w0_folds ? max(tid - 64, 0) : tid;
     const int rps = nst >> w4s;                          // rows per staging pass
-    const int npass = (kVChunk + rps - 1) / rps;         // <= 8
+    const int npass = (kVChunk + rps - 1) / rps;         // 1 / 2 / 2 for slice widths 8 / 16 / 32; <= 8 for a whole head_dim-128 row
     const int r0 = sid >> w4s, c4 = sid & ((1 << w4s) - 1);
     float o_s = 0.0f;
     v4f o_f = {0.f, 0.f, 0.f, 0.f};
@@ -2026,12 +2048,16 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
     // is shorter than an HBM round trip: the fold of 256 timesteps takes ~1 us)
     struct VRegs { v4f v[8]; };
     VRegs vra, vrb;
-    auto v_issue = [&](VRegs& R, int c0) {
-        if (!stager) return;
+    // every_wave: the two requests in front of the softmax are made by wave 0 as well (it discards them) -- loads behind
+    // a branch make hipcc's wait for the scores conservative, i.e. a wait for the V rows
+    auto v_issue = [&](VRegs& R, int c0, bool every_wave = false) {
+        if (!every_wave && !stager) return;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (u < npass) {                             // (compile-time for the instantiated slice widths)
-                const int t = min(c0 + r0 + u * rps, np - 1);
+                // clamped to the cache, not to the context: rows past the current position are allocated memory whose
+                // contents are masked at commit time, and the address then does not wait for the position
+                const int t = min(c0 + r0 + u * rps, a.seq_len - 1);
                 R.v[u] = *(const v4f*)(vbase + (size_t)t * kvd + 4 * c4);
             }
         }
@@ -2047,49 +2073,65 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
     // registers for the exp pass); the first two V chunks follow and travel under the softmax.
     // The exact sum wants power-of-two blocks of <= 64 terms in registers, one lane each, read conflict-free: besides the
     // contiguous row p[] a copy padded by 4 floats per block goes into the (still unused) first V tile.
+    // Nothing above depends on the position: the score row (clamped to its allocated stride; entries past the context are
+    // masked below) and the first two V chunks are requested before the position itself has arrived -- one memory round
+    // trip less in front of the max.
+    // The position is requested FIRST and unconditionally (operator calls pass it by value and have no state: they read a
+    // word of the rope table instead): loads retire in order, so a position load behind the V rows -- or one in a basic block
+    // of its own, which hipcc closes with vmcnt(0) -- would make every wave wait for its whole V prefetch before the max.
+    const int* pos_ptr = a.pos_override >= 0 ? (const int*)a.rope : &a.st->pos;
+    const int pos_mem = *pos_ptr;
+    __builtin_amdgcn_sched_barrier(0);
+    float sv[kAoSv];
+#pragma unroll
+    for (int u = 0; u < kAoSv; ++u) sv[u] = src[min(u * kAoThreads + tid, a.att_stride - 1)];
+    __builtin_amdgcn_sched_barrier(0);
+    v_issue(vra, 0, true);
+    v_issue(vrb, K, true);                               // (row indices are clamped to the cache)
+    __builtin_amdgcn_sched_barrier(0);
+    ATT_STAMP(1);
+    const int pos = __builtin_amdgcn_readfirstlane(a.pos_override >= 0 ? a.pos_override : pos_mem);     // wave-uniform -> SGPR
+    const int np = pos + 1;
+    const int npad = (np + 255) & ~255;                  // whole 64 x (npad/64) blocks for the exact sum
     int bl = 4;
     while (64 * bl < np) bl <<= 1;                       // 4 .. 64 for np <= 4096
     const bool padded = a.strict && bl <= 64;
     const int blsh = __builtin_ctz(bl);
     float* esc = vbuf0;                                  // (np/bl) x (bl + 4) floats <= 4352 <= one V tile of any slice width
     float m = -__builtin_inff();
-    const bool one_trip = np <= 16 * kWG;
-    float sv[16];
+    const bool one_trip = np <= kAoSv * kAoThreads;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) sv[u] = src[min(u * kWG + tid, np - 1)];
-    __builtin_amdgcn_sched_barrier(0);
-    v_issue(vra, 0);
-    if (K < np) v_issue(vrb, K);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int u = 0; u < kAoSv; ++u) sv[u] = (u * kAoThreads + tid < np) ? sv[u] : -__builtin_inff();
 #pragma unroll
-    for (int u = 0; u < 16; ++u) m = fmaxf(m, sv[u]);
-    for (int t0 = 16 * kWG; t0 < np; t0 += 16 * kWG) {   // rows beyond 4096 positions
-        float s2[16];
+    for (int u = 0; u < kAoSv; ++u) m = fmaxf(m, sv[u]);
+    for (int t0 = kAoSv * kAoThreads; t0 < np; t0 += kAoSv * kAoThreads) {   // rows beyond 4096 positions
+        float s2[kAoSv];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) s2[u] = src[min(t0 + u * kWG + tid, np - 1)];
+        for (int u = 0; u < kAoSv; ++u) s2[u] = src[min(t0 + u * kAoThreads + tid, np - 1)];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) m = fmaxf(m, s2[u]);
+        for (int u = 0; u < kAoSv; ++u) m = fmaxf(m, s2[u]);
     }
-    m = block_max(m, red);                               // (its barriers also publish etab)
-    ATT_STAMP(1);
+    ATT_STAMP(2);
+    m = block_max_n<kAoWaves>(m, red);                               // (its barriers also publish etab)
+    ATT_STAMP(3);
     float part = 0.0f;
     const int nblk_terms = ((np + bl - 1) >> blsh) << blsh;
     if (one_trip) {
         // exps in groups of four (their f64 chains interleave; a guard around each one would serialise them), whole groups
         // past the padded row skipped
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (g * 4 * kWG < npad) {
+        for (int g = 0; g < kAoSv / 4; ++g) {
+            if (g * 4 * kAoThreads < npad) {
                 float ev[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int t = (g * 4 + u) * kWG + tid;
+                    const int t = (g * 4 + u) * kAoThreads + tid;
                     const float e = q3_expf_t(t < np ? sv[g * 4 + u] - m : 0.0f, etab);
                     ev[u] = t < np ? e : 0.0f;           // +0.0 padding leaves every partial sum unchanged
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int t = (g * 4 + u) * kWG + tid;
+                    const int t = (g * 4 + u) * kAoThreads + tid;
                     part = part + ev[u];
                     if constexpr (P_LDS) {
                         // masked-off stores go to a dummy word instead of sitting behind a branch: LLVM sinks the whole exp
@@ -2104,19 +2146,19 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
             }
         }
     } else {
-        for (int t0 = 0; t0 < npad; t0 += 4 * kWG) {
+        for (int t0 = 0; t0 < npad; t0 += 4 * kAoThreads) {
             float s2[4], ev[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) s2[u] = src[min(t0 + u * kWG + tid, np - 1)];
+            for (int u = 0; u < 4; ++u) s2[u] = src[min(t0 + u * kAoThreads + tid, np - 1)];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int t = t0 + u * kWG + tid;
+                const int t = t0 + u * kAoThreads + tid;
                 const float e = q3_expf_t(t < np ? s2[u] - m : 0.0f, etab);
                 ev[u] = t < np ? e : 0.0f;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int t = t0 + u * kWG + tid;
+                const int t = t0 + u * kAoThreads + tid;
                 if (t < npad) {
                     part = part + ev[u];
                     p[t] = ev[u];
@@ -2126,22 +2168,25 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
         }
     }
     __syncthreads();
-    ATT_STAMP(2);
+    ATT_STAMP(4);
     float sum;
     if (a.strict) {
-        if (padded) sum = seq_sum_blocks(esc, (np + bl - 1) >> blsh, bl, bl + kSpecPad, nullptr);
-        else sum = seq_sum_blocks(p, 64, npad >> 6, npad >> 6, nullptr);    // rows beyond 4096 positions: 64 longer blocks out of LDS
-    } else sum = block_sum_fast(part, red);
-    ATT_STAMP(3);
+        if (wave == 0) {                                 // one wave walks the blocks; the other 15 would only fight it for LDS
+            if (padded) sum = seq_sum_blocks(esc, (np + bl - 1) >> blsh, bl, bl + kSpecPad, nullptr);
+            else sum = seq_sum_blocks(p, 64, npad >> 6, npad >> 6, nullptr);    // rows beyond 4096 positions: 64 longer blocks out of LDS
+            if (tid == 0) red[0] = sum;
+        }
+        __syncthreads();                                 // (also: the blocks in the first V tile have been read)
+        sum = red[0];
+    } else sum = block_sum_fast_n<kAoWaves>(part, red);
+    ATT_STAMP(5);
     const float inv = 1.0f / sum;
-    __syncthreads();                                     // (the exact sum read its blocks out of the first V tile)
     // reference order: p stays unnormalised, the staging threads form (e * inv) * v themselves (same two roundings as
     // normalising the row first, layers.rs:503-505 then 406-417) -- one pass over the row and one barrier less
     if (!a.strict) {
-        for (int t = tid; t < np; t += kWG) p[t] = p[t] * inv;
+        for (int t = tid; t < np; t += kAoThreads) p[t] = p[t] * inv;
         __syncthreads();
     }
-    ATT_STAMP(4);
 
     // ---- out[e] = sum_t p[t] * V[t][e]  (layers.rs:406-417), V slices staged kVChunk timesteps at a time
     constexpr int VLD = kVChunk + kVPad;
@@ -2210,7 +2255,7 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
                 }
             }
         } else {
-            for (int tb = wave * tpw; tb < cnt; tb += kWaves * tpw) {
+            for (int tb = wave * tpw; tb < cnt; tb += kAoWaves * tpw) {
                 const int t = tb + sub;
                 if (t < cnt) {
                     const float wt = pbuf[t];
@@ -2229,13 +2274,63 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
     v_commit(vra, 0, 0);
     if (2 * K < np) v_issue(vra, 2 * K);
     __syncthreads();
+    if (w0_folds && a.strict && wave == 0) {
+        // The chain wave (reference order, slices of 8 / 16): one uninterrupted stream of adds over all chunks.  It meets the
+        // staging waves' per-chunk barrier 16 timesteps before the end of its chunk -- every read of the current tile has
+        // been issued by then, and the staging waves, a whole chunk ahead, are already waiting there -- and uses the last
+        // 16 adds to bring in the head of the next tile, so no LDS latency and no barrier sits between two chunks.
+        // (Lanes >= w run along on the last row and are dropped at the store: the barrier stays outside divergent code.)
+        const int row = min(tid, w - 1);
+        auto fold4 = [&](v4f x) {
+            o_s = o_s + x.x;
+            o_s = o_s + x.y;
+            o_s = o_s + x.z;
+            o_s = o_s + x.w;
+        };
+        v4f av[4], bv[4];
+        {
+            const v4f* v0 = (const v4f*)(vbuf0 + row * VLD);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) av[u] = v0[u];
+        }
+        for (int c0 = 0, buf = 0; c0 < np; c0 += K, buf ^= 1) {
+            const int cnt = min(K, np - c0);
+            const int nq8 = ((cnt + 31) >> 5) << 3;          // float4 steps, whole blocks of 8 (zero padded, <= K/4)
+            const v4f* vr = (const v4f*)(vbuf0 + buf * (K + kVPad) * w + row * VLD);
+            const v4f* vn = (const v4f*)(vbuf0 + (buf ^ 1) * (K + kVPad) * w + row * VLD);
+            int q = 0;
+            for (; q + 8 < nq8; q += 8) {                    // every 32-timestep block but the chunk's last: one basic block
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { bv[u] = vr[q + 4 + u]; fold4(av[u]); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { av[u] = vr[q + 8 + u]; fold4(bv[u]); }
+                // one LDS read in the issue slot behind every fourth add: the reads of a block issued back to back cost the
+                // chain ~3 cycles per timestep (a dependent add issues every 10 cycles, anything else fits in between)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
+            }
+            {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { bv[u] = vr[q + 4 + u]; fold4(av[u]); }
+                __syncthreads();                             // the staging waves' barrier of this chunk: tile c+1 is complete
+                if (c0 + K < np) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) av[u] = vn[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) fold4(bv[u]);
+            }
+        }
+    } else
     for (int c0 = 0; c0 < np; c0 += 2 * K) {
         if (c0 + K < np) {
             v_commit(vrb, c0 + K, 1);
             if (c0 + 3 * K < np) v_issue(vrb, c0 + 3 * K);
         }
         fold(c0, 0);
-        if (c0 == 0) ATT_STAMP(5);
         __syncthreads();
         if (c0 + K >= np) break;
         if (c0 + 2 * K < np) {
@@ -2259,9 +2354,9 @@ __global__ __launch_bounds__(kWG) void k_attn_out(const AttnArgs a) {
         __syncthreads();
         if (sub == 0) *(v4f*)(opart + wave * w + 4 * li) = o_f;
         __syncthreads();
-        for (int i = tid; i < w; i += kWG) {
+        for (int i = tid; i < w; i += kAoThreads) {
             float r = opart[i];
-            for (int ww = 1; ww < kWaves; ++ww) r = r + opart[ww * w + i];
+            for (int ww = 1; ww < kAoWaves; ++ww) r = r + opart[ww * w + i];
             out[i] = r;
         }
     }
