@@ -229,6 +229,7 @@ struct q3_engine {
     SamplerState* d_sampler = nullptr;
     float *d_probs = nullptr, *d_sp = nullptr;
     unsigned long long* d_keys = nullptr;
+    size_t keys_n2 = 0;
     SampleArgs sargs{};
     int enqueue_sample();
 
@@ -980,7 +981,8 @@ int q3_sampler_set(q3_engine* e, float temperature, float topp, uint64_t rng_see
         HIP_TRY(hipMalloc((void**)&e->d_sampler, sizeof(SamplerState)));
         HIP_TRY(hipMalloc((void**)&e->d_probs, 4 * (size_t)kSampThreads * blen));
         HIP_TRY(hipMalloc((void**)&e->d_sp, 4 * (size_t)kSampThreads * blen));
-        HIP_TRY(hipMalloc((void**)&e->d_keys, 8 * n2));
+        HIP_TRY(hipMalloc((void**)&e->d_keys, 2 * 8 * n2));
+        e->keys_n2 = n2;
     }
     SamplerState h{rng_seed, temperature, topp, {0, 0, 0, 0}};
     int rc = set_max_smem((const void*)k_sample, 4 * kSegFloats);
@@ -992,6 +994,7 @@ int q3_sampler_set(q3_engine* e, float temperature, float topp, uint64_t rng_see
     a.blen = blen;
     a.probs = e->d_probs;
     a.keys = e->d_keys;
+    a.keys2_off = (long long)e->keys_n2;
     a.sp = e->d_sp;
     a.ss = e->d_sampler;
     a.st = e->d_state;
@@ -1425,7 +1428,7 @@ int q3_op_sample(const float* logits, size_t n, float temperature, float topp, u
     State st{};
     st.step = 1;                                            // "one forward done": the draw is stored in out_tokens[0]
     if ((rc = dl.upload(logits, 4 * n)) || (rc = dp.alloc(4 * (size_t)kSampThreads * blen)) ||
-        (rc = ds.alloc(4 * (size_t)kSampThreads * blen)) || (rc = dk.alloc(8 * n2)) || (rc = dss.upload(&h, sizeof(h))) ||
+        (rc = ds.alloc(4 * (size_t)kSampThreads * blen)) || (rc = dk.alloc(2 * 8 * n2)) || (rc = dss.upload(&h, sizeof(h))) ||
         (rc = dst.upload(&st, sizeof(st))) || (rc = dout.alloc(16)))
         return rc;
     if ((rc = set_max_smem((const void*)k_sample, 4 * kSegFloats))) return rc;
@@ -1436,6 +1439,7 @@ int q3_op_sample(const float* logits, size_t n, float temperature, float topp, u
     a.probs = dp.as<float>();
     a.sp = ds.as<float>();
     a.keys = dk.as<unsigned long long>();
+    a.keys2_off = (long long)n2;
     a.ss = dss.as<SamplerState>();
     a.st = dst.as<State>();
     a.out_tokens = dout.as<int32_t>();
