@@ -65,6 +65,9 @@ def main():
         btoks = t.generate_greedy(bfirst, a.prefill, a.decode)
         same = (bfirst == first) and (btoks == toks)
         nbytes = os.path.getsize(path)
+        kv_dim = shape.n_kv_heads * shape.head_dim
+        avg_np = a.prefill + (a.decode + 1) / 2.0           # rows 0..pos are read at position pos
+        kv_bytes = 2 * 4 * kv_dim * shape.n_layers * avg_np
     print(json.dumps({
         "metric": "chat_prefill_decode_tokens_per_second", "unit": "tok/s", "n_gpus": 1,
         "prefill_tok_s": round(a.prefill / bpre_s, 2), "prefill_sequential_tok_s": round(a.prefill / pre_s, 2),
@@ -72,6 +75,9 @@ def main():
         "batched_prefill_identical_to_sequential": bool(same),
         "prefill_ms_per_token": round(1e3 * bpre_s / a.prefill, 4), "decode_ms_per_token": round(1e3 * dec_s / a.decode, 4),
         "decode_hbm_frac_of_8TBps": round(nbytes / (dec_s / a.decode) / 8e12, 4),
+        # weights + the K and V rows every decode step reads (f32, all layers), averaged over the decoded positions
+        "decode_hbm_frac_of_8TBps_weights_plus_kv": round((nbytes + kv_bytes) / (dec_s / a.decode) / 8e12, 4),
+        "decode_kv_bytes_per_token_avg": int(kv_bytes),
         "dtype": "int8 weights x int8 activations, f32 accumulate (reference order)", "data": "synthetic",
         "config": {"workload": f"{a.shape} Q8 chat pattern: {a.prefill}-token prefill (32 positions per weight pass, sequential-equivalent) + {a.decode}-token "
                                f"greedy decode, ctx {a.ctx}", "checkpoint_bytes": nbytes, "seed": a.seed},
