@@ -457,6 +457,39 @@ __host__ __device__ inline size_t attn_gqa_smem_bytes(int hd, int kv_mul, int se
 #else
 #define GQA_STAMP(i) do { } while (0)
 #endif
+// head h's hd outputs of stream sbi: plain f32 store, plus (pack_q != nullptr) the Wo matmul's quantized operand
+__device__ __forceinline__ void gqa_store(const AttnArgs& a0, size_t sbi, int h, int hd, int lane, const float (&o)[4]) {
+    float* out = a0.xb + sbi * a0.sb_xb + (size_t)h * hd;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (lane + 64 * u < hd) out[lane + 64 * u] = o[u];
+    if (a0.pack_q != nullptr) {
+        // the Wo matmul's activation prologue, fused: quantize this head's hd outputs (hd % G == 0, so its groups
+        // are whole) exactly as tensor.rs:91-119 and store them in the packed operand order of q3_batch.h
+        const int G = a0.group, upg = G >> 6, nj = G >> 6;
+        const int ngx = (a0.n_heads * hd) / G;
+        const int nt = (int)(sbi >> 4), s = (int)(sbi & 15);
+        float mu[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mu[u] = group_max_f32((lane + 64 * u < hd) ? fabsf(o[u]) : 0.0f, 64);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (lane + 64 * u < hd) {
+                float m = mu[u];
+                if (upg >= 2) m = fmaxf(mu[u & ~1], mu[u | 1]);
+                if (upg >= 4) m = fmaxf(fmaxf(mu[0], mu[1]), fmaxf(mu[2], mu[3]));
+                const float scale = m / 127.0f;
+                const int qv = (scale != 0.0f) ? quant_round_i8(o[u] / scale) : 0;
+                const int k0 = h * hd + 64 * u + lane;
+                const int g = k0 / G, within = (k0 % G) >> 4;
+                const int qq = within / nj, j = within % nj;
+                a0.pack_q[((((size_t)nt * ngx + g) * nj + j) * 64 + (qq * 16 + s)) * 16 + (k0 & 15)] = (int8_t)qv;
+                if ((k0 % G) == 0) a0.pack_s[((size_t)nt * ngx + g) * 16 + s] = scale;
+            }
+        }
+    }
+}
+
 // HD_T / KVM_T: head_dim and kv_mul as compile-time constants for the listed models (128 with 2 or 4 query heads per kv
 // head) -- the staging index arithmetic (row = idx / (hd/4), ...) then folds to a pointer increment per slot; 0 = read
 // them from the arguments.
@@ -677,36 +710,255 @@ __global__ __launch_bounds__(512) void k_attn_gqa(const AttnArgs a0) {
         __syncthreads();
     }
     GQA_STAMP(4);
-    if (!kwave) {
-        float* out = a0.xb + sbi * a0.sb_xb + (size_t)h * hd;
+    if (!kwave) gqa_store(a0, sbi, h, hd, lane, o);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_attn_gqa with the roles split by wave (head_dim 128, KVM = 2 or 4 query heads per kv head; 512 threads): waves
+// 0..KVM-1 own one query head each and do nothing but arithmetic -- the score dots, the softmax, the two V chains per lane
+// -- while the other 8-KVM waves only move data: the K (then V) chunks travel global -> registers -> one of TWO LDS tiles,
+// two chunks ahead of the arithmetic, with ONE barrier per chunk.  In k_attn_gqa every wave staged and then computed: at a
+// context of 2,048 positions a 64-timestep chunk cost 4,300 cycles in the score loop (commit 870 + issue 1,020 + dots 2,100
+// + two barriers) and 3,400 in the V loop; here the head waves see the dots / the fold and one barrier.  During the
+// softmax the first KVM staging waves take every other 64-entry block of their head's exps.  Same operations in the same
+// order as k_attn_gqa (and k_attn in reference-order mode): bit-identical results.
+// ------------------------------------------------------------------------------------------------
+constexpr int kG2Threads = 512, kG2Waves = 8, kG2Tch = 64, kG2Hd = 128;
+__host__ __device__ inline size_t attn_gqa2_smem_bytes(int kv_mul, int seq_len) {
+    return 4 * ((size_t)(kv_mul + 1) * kG2Hd * 3 + (size_t)kv_mul * gqa_att_stride(seq_len) + 64 + 2 * (size_t)kG2Tch * (kG2Hd + kKPad));
+}
+template <int KVM>
+__global__ __launch_bounds__(kG2Threads) void k_attn_gqa2(const AttnArgs a0) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    GQA_STAMP(0);
+    constexpr int hd = kG2Hd, kld = hd + kKPad, TCH = kG2Tch, nw = KVM + 1;
+    constexpr int NST = (kG2Waves - KVM) * 64;                 // staging threads
+    constexpr int NF4 = TCH * (hd / 4);                        // float4 per chunk
+    constexpr int NSLOT = (NF4 + NST - 1) / NST;               // 8 (KVM 4) / 6 (KVM 2) staging registers per set
+    constexpr int TILE = TCH * kld;
+    const int kvh = blockIdx.x;
+    const size_t sbi = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool head = wave < KVM, kwave = wave == KVM, stager = wave >= KVM;
+    const int sid = tid - KVM * 64;                            // staging thread index (stagers only)
+    const bool own_k = a0.k_in_cache == 0;
+    const int h = kvh * KVM + (head ? wave : 0);
+    const size_t kvd = (size_t)a0.n_kv_heads * hd;
+    const int ast = gqa_att_stride(a0.seq_len);
+
+    float* q_s = (float*)smem_raw;                 // [KVM][hd]
+    float* k_s = q_s + KVM * hd;                   // [hd]
+    float* raw = k_s + hd;                         // [nw][hd]
+    float* sq = raw + nw * hd;                     // [nw][hd]
+    float* att_l = sq + nw * hd;                   // [KVM][ast]
+    float* red = att_l + (size_t)KVM * ast;        // [64]: per-head max
+    float* tiles = red + 64;                       // 2 x [TCH][kld]  (V: [TCH][hd])
+
+    const State* st = a0.st + sbi;
+    const int pos = __builtin_amdgcn_readfirstlane(a0.pos_override >= 0 ? a0.pos_override : st->pos);
+    const int np = pos + 1;
+    const float* qsrc = a0.q + sbi * a0.sb_q + (size_t)h * hd;
+    const float* ksrc = a0.k_raw + sbi * a0.sb_kraw + (size_t)kvh * hd;
+    float* key_cache = a0.key_cache + sbi * a0.sb_kv;
+    const float* kbase = key_cache + (size_t)kvh * hd;
+    const float* vbase = a0.value_cache + sbi * a0.sb_kv + (size_t)kvh * hd;
+    float* att = att_l + (size_t)(head ? wave : 0) * ast;
+    const float* cs = a0.rope + (size_t)pos * hd;
+    const int skip = own_k ? pos : -1;             // this row of the K cache is produced here, not read
+
+    v4f ra[NSLOT], rb[NSLOT];
+    // rows clamped to the context (valid, written rows); float4 slots past the chunk re-read its last one
+    auto issue = [&](v4f (&R)[NSLOT], const float* gbase, int t0) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (lane + 64 * u < hd) out[lane + 64 * u] = o[u];
-        if (a0.pack_q != nullptr) {
-            // the Wo matmul's activation prologue, fused: quantize this head's hd outputs (hd % G == 0, so its groups
-            // are whole) exactly as tensor.rs:91-119 and store them in the packed operand order of q3_batch.h
-            const int G = a0.group, upg = G >> 6, nj = G >> 6;
-            const int ngx = (a0.n_heads * hd) / G;
-            const int nt = (int)(sbi >> 4), s = (int)(sbi & 15);
-            float mu[4];
+        for (int u = 0; u < NSLOT; ++u) {
+            const int idx = min(sid + u * NST, NF4 - 1);
+            const int row = min(t0 + (idx >> 5), np - 1), c = idx & 31;
+            R[u] = *(const v4f*)(gbase + (size_t)row * kvd + 4 * c);
+        }
+    };
+    auto commit = [&](const v4f (&R)[NSLOT], float* tile, int ld, int t0, int skip_row) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) mu[u] = group_max_f32((lane + 64 * u < hd) ? fabsf(o[u]) : 0.0f, 64);
+        for (int u = 0; u < NSLOT; ++u) {
+            const int idx = sid + u * NST;
+            const int row = idx >> 5, c = idx & 31;
+            if (idx < NF4 && t0 + row < np && t0 + row != skip_row) *(v4f*)(tile + row * ld + 4 * c) = R[u];
+        }
+    };
+    // the position's own key row (normalised + rotated here) goes into the tile that holds timestep pos
+    auto fix_k = [&](float* tile, int t0) {
+        if (kwave && own_k && pos >= t0 && pos < t0 + TCH) {
+            tile[(pos - t0) * kld + lane] = k_s[lane];
+            tile[(pos - t0) * kld + lane + 64] = k_s[lane + 64];
+        }
+    };
+
+    // ---- raw q heads / raw k row, norm weights and rope pairs; the staging waves request K chunks 0 and 1
+    float r[2] = {0.0f, 0.0f};
+    RopeRegs rr;
+    if (wave <= KVM) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (lane + 64 * u < hd) {
-                    float m = mu[u];
-                    if (upg >= 2) m = fmaxf(mu[u & ~1], mu[u | 1]);
-                    if (upg >= 4) m = fmaxf(fmaxf(mu[0], mu[1]), fmaxf(mu[2], mu[3]));
-                    const float scale = m / 127.0f;
-                    const int qv = (scale != 0.0f) ? quant_round_i8(o[u] / scale) : 0;
-                    const int k0 = h * hd + 64 * u + lane;
-                    const int g = k0 / G, within = (k0 % G) >> 4;
-                    const int qq = within / nj, j = within % nj;
-                    a0.pack_q[((((size_t)nt * ngx + g) * nj + j) * 64 + (qq * 16 + s)) * 16 + (k0 & 15)] = (int8_t)qv;
-                    if ((k0 % G) == 0) a0.pack_s[((size_t)nt * ngx + g) * 16 + s] = scale;
+        for (int u = 0; u < 2; ++u) r[u] = kwave ? (own_k ? ksrc[lane + 64 * u] : 0.0f) : qsrc[lane + 64 * u];
+        rope_regs_load(rr, kwave ? a0.k_norm_w : a0.q_norm_w, cs, hd);
+    }
+    if (stager) {
+        issue(ra, kbase, 0);
+        if (TCH < np) issue(rb, kbase, TCH);
+    }
+    if (wave <= KVM) {
+        float* raw_w = raw + wave * hd;
+        raw_w[lane] = r[0];
+        raw_w[lane + 64] = r[1];
+        wave_lds_sync();
+        if (head || own_k) wave_norm_rope(kwave ? k_s : q_s + wave * hd, raw_w, sq + wave * hd, rr, hd, 1);   // layers.rs:346-372
+        wave_lds_sync();
+        if (kwave && own_k) {                                   // K is normalised + rotated in place in the cache
+            float* krow = key_cache + (size_t)pos * kvd + (size_t)kvh * hd;
+            krow[lane] = k_s[lane];
+            krow[lane + 64] = k_s[lane + 64];
+        }
+    }
+    const float scale = 1.0f / sqrtf((float)hd);   // (head_dim as f32).sqrt().recip()
+    if (stager) {
+        commit(ra, tiles, kld, 0, skip);
+        fix_k(tiles, 0);
+        if (2 * TCH < np) issue(ra, kbase, 2 * TCH);
+    }
+    __syncthreads();
+    GQA_STAMP(1);
+
+    // ---- scores: att[t] = (q . K[t]) * scale, one timestep per lane                layers.rs:391-401
+    auto dots = [&](const float* tile, int t0) {
+        const int t = lane;
+        if (t0 + t < np) {
+            const v4f* k4 = (const v4f*)(tile + t * kld);
+            const v4f* q4 = (const v4f*)(q_s + wave * hd);
+            float dot = -0.0f;
+#pragma unroll
+            for (int i = 0; i < hd / 4; i += 8) {
+                v4f kk[8], qq[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { kk[u] = k4[i + u]; qq[u] = q4[i + u]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    float p = qq[u].x * kk[u].x; dot = dot + p;
+                    p = qq[u].y * kk[u].y; dot = dot + p;
+                    p = qq[u].z * kk[u].z; dot = dot + p;
+                    p = qq[u].w * kk[u].w; dot = dot + p;
                 }
             }
+            att[t0 + t] = dot * scale;
         }
+    };
+    for (int c0 = 0; c0 < np; c0 += 2 * TCH) {
+        if (stager && c0 + TCH < np) {
+            commit(rb, tiles + TILE, kld, c0 + TCH, skip);
+            fix_k(tiles + TILE, c0 + TCH);
+            if (c0 + 3 * TCH < np) issue(rb, kbase, c0 + 3 * TCH);
+        }
+        if (head) dots(tiles, c0);
+        __syncthreads();
+        if (c0 + TCH >= np) break;
+        if (stager && c0 + 2 * TCH < np) {
+            commit(ra, tiles, kld, c0 + 2 * TCH, skip);
+            fix_k(tiles, c0 + 2 * TCH);
+            if (c0 + 4 * TCH < np) issue(ra, kbase, c0 + 4 * TCH);
+        }
+        if (head) dots(tiles + TILE, c0 + TCH);
+        __syncthreads();
+    }
+    GQA_STAMP(2);
+
+    // ---- softmax, one wave per head (+ one helper wave for the exps)            layers.rs:495-506
+    if (stager) {                                   // V chunks 0 and 1 travel under the softmax
+        issue(ra, vbase, 0);
+        if (TCH < np) issue(rb, vbase, TCH);
+    }
+    const int npad = (np + 255) & ~255;
+    if (head) {
+        float m = -__builtin_inff();
+        for (int t = lane; t < np; t += 64) m = fmaxf(m, att[t]);
+        m = group_max_f32(m, 64);
+        if (lane == 0) red[wave] = m;
+    }
+    __syncthreads();
+    {
+        // head wave j takes the even 64-entry blocks of its row, staging wave KVM + j the odd ones
+        const bool helper = wave >= KVM && wave < 2 * KVM;
+        if (head || helper) {
+            const int j = head ? wave : wave - KVM;
+            float* row = att_l + (size_t)j * ast;
+            const float m = red[j];
+            for (int t = (head ? 0 : 64) + lane; t < npad; t += 128) row[t] = (t < np) ? q3_expf(row[t] - m) : 0.0f;   // +0.0 padding: sums unchanged
+        }
+    }
+    __syncthreads();
+    if (head) {
+        float sum;
+        if (np < 256) {
+            const int nq4 = np >> 2;
+            sum = seq_chain(-0.0f, (const v4f*)att, nq4);
+            for (int t = nq4 << 2; t < np; ++t) sum = sum + att[t];
+        } else {
+            sum = seq_sum_blocks(att, 64, npad >> 6, npad >> 6, nullptr);
+        }
+        const float inv = 1.0f / sum;
+        for (int t = lane; t < np; t += 64) att[t] = att[t] * inv;
+        wave_lds_sync();
+    }
+    GQA_STAMP(3);
+
+    // ---- xb = sum_t att[t] * V[t]  (fill(0.0) then += in t order)              layers.rs:406-417
+    // the lane's two element chains (lane, lane + 64) advance together and share the probability reads
+    float o0 = 0.0f, o1 = 0.0f;
+    auto fold = [&](const float* tile, int t0) {
+        const int cnt = min(TCH, np - t0);
+        const v4f* w4 = (const v4f*)(att + t0);
+        const float* v0 = tile + lane;
+        int t = 0;
+        for (; t + 8 <= cnt; t += 8, v0 += 8 * hd) {
+            const v4f pa = w4[t >> 2], pb = w4[(t >> 2) + 1];
+            float x0[8], x1[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) { x0[x] = v0[x * hd]; x1[x] = v0[x * hd + 64]; }
+            const float ww[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const float p0 = ww[x] * x0[x], p1 = ww[x] * x1[x];
+                o0 = o0 + p0;
+                o1 = o1 + p1;
+            }
+        }
+        for (; t < cnt; ++t, v0 += hd) {
+            const float wt = att[t0 + t];
+            const float p0 = wt * v0[0], p1 = wt * v0[64];
+            o0 = o0 + p0;
+            o1 = o1 + p1;
+        }
+    };
+    if (stager) {
+        commit(ra, tiles, hd, 0, -1);
+        if (2 * TCH < np) issue(ra, vbase, 2 * TCH);
+    }
+    __syncthreads();
+    for (int c0 = 0; c0 < np; c0 += 2 * TCH) {
+        if (stager && c0 + TCH < np) {
+            commit(rb, tiles + TILE, hd, c0 + TCH, -1);
+            if (c0 + 3 * TCH < np) issue(rb, vbase, c0 + 3 * TCH);
+        }
+        if (head) fold(tiles, c0);
+        __syncthreads();
+        if (c0 + TCH >= np) break;
+        if (stager && c0 + 2 * TCH < np) {
+            commit(ra, tiles, hd, c0 + 2 * TCH, -1);
+            if (c0 + 4 * TCH < np) issue(ra, vbase, c0 + 4 * TCH);
+        }
+        if (head) fold(tiles + TILE, c0 + TCH);
+        __syncthreads();
+    }
+    GQA_STAMP(4);
+    if (head) {
+        const float o[4] = {o0, o1, 0.0f, 0.0f};
+        gqa_store(a0, sbi, h, hd, lane, o);
     }
 }
 
