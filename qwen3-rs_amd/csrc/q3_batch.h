@@ -840,10 +840,11 @@ __global__ __launch_bounds__(kG2Threads) void k_attn_gqa2(const AttnArgs a0) {
                 for (int u = 0; u < 8; ++u) { kk[u] = k4[i + u]; qq[u] = q4[i + u]; }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    float p = qq[u].x * kk[u].x; dot = dot + p;
-                    p = qq[u].y * kk[u].y; dot = dot + p;
-                    p = qq[u].z * kk[u].z; dot = dot + p;
-                    p = qq[u].w * kk[u].w; dot = dot + p;
+                    const v4f pr = qq[u] * kk[u];          // products are independent of the chain: packed multiplies
+                    dot = dot + pr.x;
+                    dot = dot + pr.y;
+                    dot = dot + pr.z;
+                    dot = dot + pr.w;
                 }
             }
             att[t0 + t] = dot * scale;
@@ -855,8 +856,11 @@ __global__ __launch_bounds__(kG2Threads) void k_attn_gqa2(const AttnArgs a0) {
             fix_k(tiles + TILE, c0 + TCH);
             if (c0 + 3 * TCH < np) issue(rb, kbase, c0 + 3 * TCH);
         }
+        if (c0 == 8 * TCH) GQA_STAMP(8);
         if (head) dots(tiles, c0);
+        if (c0 == 8 * TCH) GQA_STAMP(9);
         __syncthreads();
+        if (c0 == 8 * TCH) GQA_STAMP(10);
         if (c0 + TCH >= np) break;
         if (stager && c0 + 2 * TCH < np) {
             commit(ra, tiles, kld, c0 + 2 * TCH, skip);
@@ -908,7 +912,10 @@ __global__ __launch_bounds__(kG2Threads) void k_attn_gqa2(const AttnArgs a0) {
     GQA_STAMP(3);
 
     // ---- xb = sum_t att[t] * V[t]  (fill(0.0) then += in t order)              layers.rs:406-417
-    // the lane's two element chains (lane, lane + 64) advance together and share the probability reads
+    // the lane's two element chains (lane, lane + 64) advance together and share the probability reads.  (Measured and not
+    // kept: the pair as packed f32 ops -- v_pk_mul/add issue at half rate, no gain --; four consecutive elements per lane with
+    // two heads per wave and 16-byte LDS reads, also software-pipelined with one read behind each step: 41-48 cycles per
+    // timestep against 37 for this form.)
     float o0 = 0.0f, o1 = 0.0f;
     auto fold = [&](const float* tile, int t0) {
         const int cnt = min(TCH, np - t0);
@@ -945,8 +952,11 @@ __global__ __launch_bounds__(kG2Threads) void k_attn_gqa2(const AttnArgs a0) {
             commit(rb, tiles + TILE, hd, c0 + TCH, -1);
             if (c0 + 3 * TCH < np) issue(rb, vbase, c0 + 3 * TCH);
         }
+        if (c0 == 8 * TCH) GQA_STAMP(11);
         if (head) fold(tiles, c0);
+        if (c0 == 8 * TCH) GQA_STAMP(12);
         __syncthreads();
+        if (c0 == 8 * TCH) GQA_STAMP(13);
         if (c0 + TCH >= np) break;
         if (stager && c0 + 2 * TCH < np) {
             commit(ra, tiles, hd, c0 + 2 * TCH, -1);

@@ -43,6 +43,7 @@ constexpr float kEps = 1e-6f;  // layers.rs:6
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));   // two lock-step f32 chains: v_pk_mul_f32 / v_pk_add_f32 (IEEE per element)
 
 // ------------------------------------------------------------------------------------------------
 // cross-lane helpers.  DPP controls: quad_perm(1,0,3,2)=0xB1, quad_perm(2,3,0,1)=0x4E,

@@ -26,6 +26,8 @@ for idx in range(0, 40):
     if st[4] <= st[0] or st[4] - st[0] > 10**9:
         continue
     c8 = [buf[i] for i in range(8, 14)]
-    if c8[0]:
+    if c8[0] and c8[3] > c8[2]:      # k_attn_gqa2: wave 0 at chunk 8 of each loop
+        print("   chunk 8, wave 0: score dots %d + barrier wait %d;  V fold %d + barrier wait %d" % (c8[1] - c8[0], c8[2] - c8[1], c8[4] - c8[3], c8[5] - c8[4]))
+    elif c8[0]:
         print("   chunk 8 of the scores loop: commit %d  barrier %d  issue-next %d  dots %d  barrier %d" % tuple(c8[i + 1] - c8[i] for i in range(5)))
     print(f"launch {idx}: " + "  ".join(f"{names[i]} {st[i + 1] - st[i]}" for i in range(4)) + f"  total {st[4] - st[0]} cycles")
