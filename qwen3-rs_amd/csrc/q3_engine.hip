@@ -221,6 +221,7 @@ struct q3_engine {
     hipGraph_t graph = nullptr, graph_long = nullptr;
     hipGraphExec_t graph_exec = nullptr, graph_long_exec = nullptr;
     float* d_att_priv = nullptr;
+    int cmax_stride = 0;
     int att_stride = 0;
     int split_pos = 256;
     BatchCtx* batch = nullptr;                 // batched decode state (q3_batch_init), see q3_batch_host.inc
@@ -558,7 +559,8 @@ int q3_engine::build_plan() {
     const int slice_w = attn_slice_w(hd, cfg.n_heads, n_cu);
     const int nsl = hd / slice_w;
     const bool use_att_global = S > att_lds_max;
-    HIP_TRY(hipMalloc((void**)&d_att, 4 * (size_t)cfg.n_heads * att_stride));
+    cmax_stride = (int)((((size_t)S + 63) / 64 + 63) & ~(size_t)63);
+    HIP_TRY(hipMalloc((void**)&d_att, 4 * (size_t)cfg.n_heads * ((size_t)att_stride + cmax_stride)));   // score rows, then their 64-block maxima
     HIP_TRY(hipMalloc((void**)&d_att_priv, 4 * (size_t)cfg.n_heads * nsl * att_stride));
     if (env_int("Q3_STAMPS", 0)) {
         HIP_TRY(hipMalloc((void**)&d_stamps, 8 * 8 * (size_t)(5 * L + 4)));
@@ -743,6 +745,8 @@ int q3_engine::build_plan() {
         A.aa.q_out = nullptr;
         const ScoresShape ss = scores_shape(hd, A.aa.n_heads, A.aa.n_kv_heads, S);
         A.scores_kvm = ss.kvm;
+        A.aa.att_cmax = B.aa.att_cmax = (ss.kvm && env_int("Q3_ATT_CMAX", 1)) ? d_att + (size_t)A.aa.n_heads * att_stride : nullptr;
+        A.aa.cmax_stride = B.aa.cmax_stride = cmax_stride;
         A.grid = ss.gx;
         A.grid_y = ss.gy;
         A.smem = ss.smem;

@@ -1121,6 +1121,10 @@ struct AttnArgs {
     int group;
     int slice_w;              // k_attn_out: output elements per workgroup (attn_slice_w)
     int k_in_cache;           // batched prefill: row pos of the key cache was already written by k_knorm_rope
+    // split path with k_attn_scores_kv: [n_heads][cmax_stride] maximum of every 64-timestep block of a score row, written
+    // by the scores kernel so that k_attn_out finds the row maximum without a block-wide reduction (nullptr: not available)
+    float* att_cmax;
+    int cmax_stride;
 };
 
 // LDS plan of k_attn (floats): q_s[hd] k_s[hd] raw[2hd] sq[2hd] opart[kWaves*hd] red[64] att[att_lds]
@@ -1737,7 +1741,7 @@ __host__ __device__ inline size_t attn_scores_smem_bytes(int hd) {
 __host__ __device__ inline bool attn_out_p_in_lds(int seq_len) { return ((seq_len + 255) & ~255) <= kPLds; }
 __host__ __device__ inline size_t attn_out_smem_bytes(int hd, int seq_len, int w) {
     const int pl = ((seq_len + 255) & ~255) <= kPLds ? ((seq_len + 255) & ~255) : 0;
-    return 4 * (2 * (size_t)(kVChunk + kVPad) * w + 2 * kVChunk + 64 + (size_t)16 * w + (size_t)pl) + 32 * 8;   // V / p chunk tiles double buffered; [kAoWaves][w] partials; exp2 table
+    return 4 * (2 * (size_t)(kVChunk + kVPad) * w + 2 * kVChunk + 64 + (size_t)16 * w + (size_t)pl) + 16 * 32 * 8;   // V / p chunk tiles double buffered; [kAoWaves][w] partials; one exp2 table per wave
 }
 
 __global__ __launch_bounds__(kWG) void k_attn_scores(const AttnArgs a) {
@@ -1952,6 +1956,7 @@ __global__ __launch_bounds__(kWG) void k_attn_scores_kv(const AttnArgs a) {
     ATT_STAMP(4);
     {
         const int j = wave % KVM_T, t = (wave / KVM_T) * 64 + lane;
+        float sc = -__builtin_inff();
         if (t < cnt) {
             const v4f* k4 = (const v4f*)(kbuf + t * kld);
             const v4f* q4 = (const v4f*)(q_s + j * hd);
@@ -1969,7 +1974,14 @@ __global__ __launch_bounds__(kWG) void k_attn_scores_kv(const AttnArgs a) {
                     p = qq[u].w * kk[u].w; dot = dot + p;
                 }
             }
-            a.att_global[(size_t)(kvh * KVM_T + j) * a.att_stride + t0 + t] = dot * (1.0f / sqrtf((float)hd));
+            sc = dot * (1.0f / sqrtf((float)hd));
+            a.att_global[(size_t)(kvh * KVM_T + j) * a.att_stride + t0 + t] = sc;
+        }
+        if (a.att_cmax != nullptr) {
+            // this wave's 64 timesteps are block (t0 / 64 + wave / KVM_T) of the head's row: its maximum (f32::max over the
+            // same values in any order) spares k_attn_out a block-wide reduction behind its slowest wave
+            const float wm = group_max_f32(sc, 64);
+            if (lane == 0) a.att_cmax[(size_t)(kvh * KVM_T + j) * a.cmax_stride + (t0 >> 6) + wave / KVM_T] = wm;
         }
     }
     ATT_STAMP(5);
@@ -2066,8 +2078,9 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
     constexpr int K = kVChunk;
 
     // exp2 table of q3_expf staged in LDS (a dependent global load per exp otherwise)
-    unsigned long long* etab = (unsigned long long*)(p_lds + (p_in_lds ? npad_max : 0));
-    if (tid < 32) etab[tid] = kExp2Tab[tid];
+    // (one copy per wave: with the block maxima below no barrier separates the staging of the table from its use)
+    unsigned long long* etab = (unsigned long long*)(p_lds + (p_in_lds ? npad_max : 0)) + 32 * wave;
+    if (lane < 32) etab[lane] = kExp2Tab[lane];
 
     // ---- softmax (layers.rs:495-506) into this workgroup's private probability row.  The scores are on the critical path
     // and go out first (16 independent loads per thread: one trip covers 4096 positions and the values then stay in
@@ -2086,6 +2099,10 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
     float sv[kAoSv];
 #pragma unroll
     for (int u = 0; u < kAoSv; ++u) sv[u] = src[min(u * kAoThreads + tid, a.att_stride - 1)];
+    // block maxima of the row from k_attn_scores_kv (one per lane covers 4096 positions); valid memory either way
+    const bool have_cmax = a.att_cmax != nullptr;
+    const float* cmrow = have_cmax ? a.att_cmax + (size_t)h * a.cmax_stride : src;
+    float cmv = cmrow[min(lane, (have_cmax ? a.cmax_stride : a.att_stride) - 1)];
     __builtin_amdgcn_sched_barrier(0);
     v_issue(vra, 0, true);
     v_issue(vrb, K, true);                               // (row indices are clamped to the cache)
@@ -2103,17 +2120,27 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
     const bool one_trip = np <= kAoSv * kAoThreads;
 #pragma unroll
     for (int u = 0; u < kAoSv; ++u) sv[u] = (u * kAoThreads + tid < np) ? sv[u] : -__builtin_inff();
+    if (have_cmax) {
+        // every wave finds the row maximum by itself: no barrier, so a wave that was launched late only delays its own exps
+        const int nblk64 = (np + 63) >> 6;
+        m = lane < nblk64 ? cmv : m;
+        for (int i = 64 + lane; i < nblk64; i += 64) m = fmaxf(m, cmrow[i]);     // rows beyond 4096 positions
+        m = group_max_f32(m, 64);
+        wave_lds_sync();                                 // this wave's exp2 table
+        ATT_STAMP(2);
+    } else {
 #pragma unroll
-    for (int u = 0; u < kAoSv; ++u) m = fmaxf(m, sv[u]);
-    for (int t0 = kAoSv * kAoThreads; t0 < np; t0 += kAoSv * kAoThreads) {   // rows beyond 4096 positions
-        float s2[kAoSv];
+        for (int u = 0; u < kAoSv; ++u) m = fmaxf(m, sv[u]);
+        for (int t0 = kAoSv * kAoThreads; t0 < np; t0 += kAoSv * kAoThreads) {   // rows beyond 4096 positions
+            float s2[kAoSv];
 #pragma unroll
-        for (int u = 0; u < kAoSv; ++u) s2[u] = src[min(t0 + u * kAoThreads + tid, np - 1)];
+            for (int u = 0; u < kAoSv; ++u) s2[u] = src[min(t0 + u * kAoThreads + tid, np - 1)];
 #pragma unroll
-        for (int u = 0; u < kAoSv; ++u) m = fmaxf(m, s2[u]);
+            for (int u = 0; u < kAoSv; ++u) m = fmaxf(m, s2[u]);
+        }
+        ATT_STAMP(2);
+        m = block_max_n<kAoWaves>(m, red);                               // (its barriers also publish the exp2 tables)
     }
-    ATT_STAMP(2);
-    m = block_max_n<kAoWaves>(m, red);                               // (its barriers also publish etab)
     ATT_STAMP(3);
     float part = 0.0f;
     const int nblk_terms = ((np + bl - 1) >> blsh) << blsh;
