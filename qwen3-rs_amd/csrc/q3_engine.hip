@@ -1334,6 +1334,12 @@ int q3_op_attention(float* xb, float* q, float* key_cache_layer, const float* va
         a.slice_w = slice_w;
         const ScoresShape ss = scores_shape((int)head_dim, (int)n_heads, (int)n_kv_heads, (int)seq_len);
         if ((rc = set_attn_scores_smem(ss)) || (rc = set_attn_out_smem(sm2))) return rc;
+        DevBuf dcmax;
+        if (ss.kvm && env_int("Q3_ATT_CMAX", 1)) {               // 64-timestep block maxima, as in the engine's long plan
+            a.cmax_stride = (int)(((seq_len + 63) / 64 + 63) & ~(size_t)63);
+            if ((rc = dcmax.alloc(4 * n_heads * (size_t)a.cmax_stride))) return rc;
+            a.att_cmax = dcmax.as<float>();
+        }
         launch_attn_scores(a, ss.kvm, ss.gx, ss.gy, ss.smem, 0);
         launch_attn_out(a, (unsigned)n_heads, (unsigned)nsl, sm2, 0);
         if ((rc = op_end())) return rc;

@@ -147,10 +147,15 @@ def test_attention(ops, oracle, nh, nkv, hd, S, pos):
     assert np.max(np.abs(xb - rb)) <= FAST_TOL and np.max(np.abs(q2 - rq)) <= FAST_TOL
 
 
-def test_attention_long_context(ops, oracle):
+@pytest.mark.parametrize("nh,nkv,hd,S,pos", [
+    (4, 2, 64, 4600, 4500),        # head_dim 64: per-query-head scores kernel, block-wide row maximum
+    (8, 2, 128, 4600, 4500),       # 4 query heads per kv head: shared K chunks, 71 block maxima (more than one per lane)
+    (4, 2, 128, 8500, 8400),       # 2 query heads per kv head, context > 8192: probability rows in global memory
+    (8, 2, 128, 4096, 4095),       # the last position of a 4096 context: every lane's block maximum is live
+])
+def test_attention_long_context(ops, oracle, nh, nkv, hd, S, pos):
     """pos beyond the LDS score buffer (scores go through the global scratch) and dozens of K/V chunks."""
     rng = np.random.default_rng(9)
-    nh, nkv, hd, S, pos = 4, 2, 64, 4600, 4500
     kvd = nkv * hd
     q = rng.standard_normal(nh * hd).astype(np.float32)
     K = (rng.standard_normal((S, kvd)) * 0.5).astype(np.float32)
