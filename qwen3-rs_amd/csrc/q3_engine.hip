@@ -132,6 +132,7 @@ struct Launch {
     GemvArgs ga{};
     AttnArgs aa{};
     unsigned grid = 1;
+    unsigned block = kWG;  // threads per workgroup (specialised GEMV shapes: 256 / 512 / 1024)
     size_t smem = 0;
 };
 
@@ -174,6 +175,51 @@ GemvFn pick(int G, int RU, int JU, int FIN = 0, int PF = 0) {
     return nullptr;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Shape-specialised GEMV launches (k_gemv with N_T > 0): every (prologue, epilogue, contraction length) of the listed
+// models (0.6B dim 1024 / hidden 3072, 4B 2560 / 9728, 8B 4096 / 12288, all heads x head_dim 2048 / 4096)
+// has one or more tile / workgroup-width candidates; the first entry of a role is the default, Q3_CFG_<FAMILY>=k picks the
+// k-th (sweeps: tools/r03_cfg_sweep.sh), -1 forces the generic run-time-n kernel.  Anything not listed (test shapes,
+// other group sizes) takes the generic path.
+// ------------------------------------------------------------------------------------------------
+struct GemvCfg { int pro, epi, n, wgt, ept, ru, ju, pf; GemvFn fn; };
+#define Q3_CFG(PRO, EPI, N, WGT, EPT, RU, JU, PF) \
+    {PRO, EPI, N, WGT, EPT, RU, JU, PF, (GemvFn)k_gemv<PRO, EPI, 4, RU, JU, 1, PF, N, WGT, EPT>}
+#define Q3_CFG_NORM_QKV(N, WGT, EPT, RU, JU, PF) Q3_CFG(PRO_NORM, EPI_QKV, N, WGT, EPT, RU, JU, PF), Q3_CFG(PRO_EMBED_NORM, EPI_QKV, N, WGT, EPT, RU, JU, PF)
+const GemvCfg kGemvCfgs[] = {
+    // --- QKV: RMSNorm_att + quantize + wq|wk|wv
+    Q3_CFG_NORM_QKV(1024, 1024, 1, 1, 1, 0), Q3_CFG_NORM_QKV(1024, 1024, 4, 1, 1, 0), Q3_CFG_NORM_QKV(1024, 512, 2, 2, 1, 0),
+    Q3_CFG_NORM_QKV(1024, 256, 4, 2, 1, 0),
+    Q3_CFG_NORM_QKV(2560, 1024, 4, 2, 3, 0), Q3_CFG_NORM_QKV(2560, 512, 4, 2, 3, 0),
+    Q3_CFG_NORM_QKV(4096, 1024, 4, 2, 4, 0), Q3_CFG_NORM_QKV(4096, 512, 4, 2, 4, 0), Q3_CFG_NORM_QKV(4096, 1024, 4, 1, 4, 0),
+    // --- W1|W3 + SwiGLU
+    Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 1024, 1, 2, 1, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 1024, 4, 2, 1, 0),
+    Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 512, 2, 4, 1, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 256, 4, 4, 1, 0),
+    Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 1024, 4, 2, 3, 1), Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 512, 4, 2, 3, 1),
+    Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 1024, 4, 2, 4, 1), Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 512, 4, 2, 4, 1),
+    // --- Wo behind the short-context attention kernel (xb arrives quantized): register-direct activation
+    Q3_CFG(PRO_PREQR, EPI_RESID, 2048, 256, 4, 1, 2, 0), Q3_CFG(PRO_PREQR, EPI_RESID, 2048, 512, 4, 1, 2, 0),
+    Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 256, 4, 1, 4, 0), Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 256, 4, 2, 4, 0),
+    Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 512, 4, 1, 4, 0),
+    // --- quantize + W2 (and Wo of the long-context plan)
+    Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 1024, 4, 1, 3, 0), Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 512, 4, 1, 3, 0),
+    Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 256, 4, 1, 3, 0),
+    Q3_CFG(PRO_QUANT, EPI_RESID, 9728, 1024, 4, 1, 2, 1), Q3_CFG(PRO_QUANT, EPI_RESID, 9728, 512, 4, 1, 2, 1),
+    Q3_CFG(PRO_QUANT, EPI_RESID, 12288, 1024, 4, 1, 4, 1), Q3_CFG(PRO_QUANT, EPI_RESID, 12288, 512, 4, 1, 4, 1),
+    Q3_CFG(PRO_QUANT, EPI_RESID, 2048, 512, 4, 1, 2, 0), Q3_CFG(PRO_QUANT, EPI_RESID, 2048, 256, 4, 1, 2, 0),
+    Q3_CFG(PRO_QUANT, EPI_RESID, 4096, 1024, 4, 1, 4, 0), Q3_CFG(PRO_QUANT, EPI_RESID, 4096, 512, 4, 1, 4, 0),
+};
+const GemvCfg* find_cfg(int pro, int epi, int n, int G, int which) {
+    if (G != 64 || which < 0) return nullptr;
+    const GemvCfg* last = nullptr;
+    for (const GemvCfg& c : kGemvCfgs)
+        if (c.pro == pro && c.epi == epi && c.n == n) {
+            last = &c;
+            if (which-- == 0) return &c;
+        }
+    return last;                     // an index past the last candidate selects the last one
+}
+
 int set_max_smem(const void* fn, size_t bytes) {
     if (bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return Q3_OK;
@@ -204,6 +250,8 @@ struct q3_engine {
     std::vector<QT> wq, wk, wv, wo, w1, w2, w3;
     float *d_x = nullptr, *d_q = nullptr, *d_kraw = nullptr, *d_xb = nullptr, *d_hb = nullptr, *d_logits = nullptr;
     float *d_tap = nullptr, *d_key = nullptr, *d_value = nullptr, *d_rope = nullptr, *d_att = nullptr;
+    int8_t* d_xbq = nullptr;                   // attention output quantized by k_attn_short (operand of the PRO_PREQR Wo launch)
+    float* d_xbs = nullptr;
     State* d_state = nullptr;
     int32_t* d_out_tokens = nullptr;
     int32_t* d_prompt = nullptr;               // chat-mode prefill: prompt token ids (capacity out_cap)
@@ -311,7 +359,7 @@ void launch_one(const Launch& L, q3_engine* e) {
         hipLaunchKernelGGL(k_next, dim3(1), dim3(kWG), 0, e->stream, e->d_state, e->d_argmax_slots, e->n_argmax_slots,
                            e->d_out_tokens, e->out_cap, e->d_prompt);
     } else {
-        hipLaunchKernelGGL(L.fn, dim3(L.grid), dim3(kWG), L.smem, e->stream, L.ga);
+        hipLaunchKernelGGL(L.fn, dim3(L.grid), dim3(L.block), L.smem, e->stream, L.ga);
     }
 }
 
@@ -373,6 +421,24 @@ GemvShape plan_gemv(int units, int n, int G, bool swiglu, int row_align, int n_c
     return g;
 }
 
+// grid / block / LDS of a specialised launch: one row batch (hu rows or hidden units) per wave and round; at least one
+// workgroup per CU as long as there are batches for it (fewer batches than waves: see k_gemv's wave numbering)
+void apply_cfg(Launch& Ln, GemvArgs& a, const GemvCfg& c, int units, int n_cu) {
+    const int waves = c.wgt / 64;
+    const int hu = (c.epi == EPI_SWIGLU) ? c.ru / 2 : c.ru;
+    const long nb = ((long)units + hu - 1) / hu;
+    const int wg_per_cu = c.wgt >= 1024 ? 1 : (c.wgt >= 512 ? 2 : 4);
+    long grid = (nb + waves - 1) / waves;
+    const long lower = nb < n_cu ? nb : n_cu;
+    if (grid < lower) grid = lower;
+    if (grid > (long)n_cu * wg_per_cu) grid = (long)n_cu * wg_per_cu;
+    a.vr = c.ru;
+    Ln.fn = c.fn;
+    Ln.grid = (unsigned)grid;
+    Ln.block = (unsigned)c.wgt;
+    Ln.smem = gemv_smem_bytes(c.n, 64, c.ru, false, waves, true);      // (no f32 staging: wave 0 sums out of registers)
+}
+
 }  // namespace
 
 void q3_engine::release() {
@@ -381,7 +447,7 @@ void q3_engine::release() {
     if (graph) (void)hipGraphDestroy(graph);
     if (graph_long_exec) (void)hipGraphExecDestroy(graph_long_exec);
     if (graph_long) (void)hipGraphDestroy(graph_long);
-    void* dptrs[] = {d_sampler, d_probs, d_sp, d_keys, d_prompt, d_att_priv, d_argmax_slots, d_stamps, d_blob, d_x, d_q, d_kraw, d_xb, d_hb, d_logits, d_tap, d_key, d_value, d_rope, d_att, d_state, d_out_tokens};
+    void* dptrs[] = {d_xbq, d_xbs, d_sampler, d_probs, d_sp, d_keys, d_prompt, d_att_priv, d_argmax_slots, d_stamps, d_blob, d_x, d_q, d_kraw, d_xb, d_hb, d_logits, d_tap, d_key, d_value, d_rope, d_att, d_state, d_out_tokens};
     for (void* p : dptrs)
         if (p) (void)hipFree(p);
     if (h_logits) (void)hipHostFree(h_logits);
@@ -563,8 +629,8 @@ int q3_engine::build_plan() {
     HIP_TRY(hipMalloc((void**)&d_att, 4 * (size_t)cfg.n_heads * ((size_t)att_stride + cmax_stride)));   // score rows, then their 64-block maxima
     HIP_TRY(hipMalloc((void**)&d_att_priv, 4 * (size_t)cfg.n_heads * nsl * att_stride));
     if (env_int("Q3_STAMPS", 0)) {
-        HIP_TRY(hipMalloc((void**)&d_stamps, 8 * 8 * (size_t)(5 * L + 4)));
-        HIP_TRY(hipMemset(d_stamps, 0, 8 * 8 * (size_t)(5 * L + 4)));
+        HIP_TRY(hipMalloc((void**)&d_stamps, 8 * 16 * (size_t)(5 * L + 4)));
+        HIP_TRY(hipMemset(d_stamps, 0, 8 * 16 * (size_t)(5 * L + 4)));
     }
 
     auto base_args = [&](int n) {
@@ -578,6 +644,10 @@ int q3_engine::build_plan() {
         return a;
     };
     int rc;
+    const GemvCfg* wo_preq = nullptr;
+    std::vector<Launch> wo_long;       // the long-context plan's Wo launches (k_attn_out emits no quantized operand)
+    HIP_TRY(hipMalloc((void**)&d_xbq, (size_t)ahd));
+    HIP_TRY(hipMalloc((void**)&d_xbs, 4 * (size_t)(ahd / G)));
     const int alias0 = env_int("Q3_DEBUG_ALIAS_LAYER0", 0);   // experiment: every layer streams layer 0's weights
     for (int l = 0; l < L; ++l) {
         const size_t kv_off = (size_t)l * S * kvd;
@@ -597,22 +667,27 @@ int q3_engine::build_plan() {
             }
             a.norm_w = rms_att + (size_t)l * dim;
             a.in = d_x;
-            const GemvShape gs = plan_gemv(a.total_rows, dim, G, false, hd, n_cu, small_cap);
+            const GemvCfg* cfg = find_cfg(l == 0 ? PRO_EMBED_NORM : PRO_NORM, EPI_QKV, dim, G, env_int("Q3_CFG_QKV", 0));
+            if (cfg && (hd % cfg->ru) != 0) cfg = nullptr;           // batches must not straddle the q|k|v segments
             if (l == 0) {
                 a.emb_q = tok.q;
                 a.emb_s = tok.s;
                 a.x_out = d_x;
-                Ln.fn = pick<PRO_EMBED_NORM, EPI_QKV>(G, gs.RU, gs.JU, gs.FIN, gs.PF);
-            } else {
-                Ln.fn = pick<PRO_NORM, EPI_QKV>(G, gs.RU, gs.JU, gs.FIN, gs.PF);
             }
-            a.vr = gs.RU;
-            Ln.grid = gs.grid;
-            Ln.smem = gemv_smem_bytes(dim, G, a.vr, true);
+            if (cfg) {
+                apply_cfg(Ln, a, *cfg, a.total_rows, n_cu);
+            } else {
+                const GemvShape gs = plan_gemv(a.total_rows, dim, G, false, hd, n_cu, small_cap);
+                if (l == 0) Ln.fn = pick<PRO_EMBED_NORM, EPI_QKV>(G, gs.RU, gs.JU, gs.FIN, gs.PF);
+                else Ln.fn = pick<PRO_NORM, EPI_QKV>(G, gs.RU, gs.JU, gs.FIN, gs.PF);
+                a.vr = gs.RU;
+                Ln.grid = gs.grid;
+                Ln.smem = gemv_smem_bytes(dim, G, a.vr, true);
+            }
             Ln.ga = a;
             if (!Ln.fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel instantiated for this tile shape");
             if ((rc = set_max_smem((const void*)Ln.fn, Ln.smem))) return rc;
-            if (d_stamps) { Ln.ga.stamps = d_stamps + 8 * plan.size(); Ln.ga.stamp_block = env_int("Q3_STAMP_BLOCK", 7); }
+            if (d_stamps) { Ln.ga.stamps = d_stamps + 16 * plan.size(); Ln.ga.stamp_block = env_int("Q3_STAMP_BLOCK", 7); }
             plan.push_back(Ln);
         }
         {   // QK-norm + RoPE + attention                                        layers.rs:346-419
@@ -638,13 +713,20 @@ int q3_engine::build_plan() {
             a.strict = strict;
             a.write_q = 0;
             a.debug = env_int("Q3_ABLATE", 0);
-            a.stamps = d_stamps ? d_stamps + 8 * plan.size() : nullptr;
+            a.stamps = d_stamps ? d_stamps + 16 * plan.size() : nullptr;
             Ln.aa = a;
             Ln.grid = (unsigned)cfg.n_heads;
             Ln.smem = attn_smem_bytes(hd, use_att_global ? 0 : S);
             if ((rc = set_max_smem((const void*)k_attn, Ln.smem))) return rc;
             // the short plan only ever runs at pos < split_pos
             if ((hd == 64 || hd == 128) && split_pos <= kShortMaxT && env_int("Q3_ATT_SHORT", 1)) Ln.attn_kind = 3;
+            // k_attn_short can hand Wo its operand quantized (qwen3.rs:152 fused into the attention epilogue)
+            wo_preq = Ln.attn_kind == 3 ? find_cfg(PRO_PREQR, EPI_RESID, ahd, G, env_int("Q3_CFG_WO", 0)) : nullptr;
+            if (wo_preq) {
+                Ln.aa.xbq = d_xbq;
+                Ln.aa.xbs = d_xbs;
+                Ln.aa.xb_group = G;
+            }
             plan.push_back(Ln);
         }
         {   // xq = quantize(xb); x += Wo xq                                      qwen3.rs:152-156
@@ -654,15 +736,32 @@ int q3_engine::build_plan() {
             a.seg[0] = Seg{wo[lw].q, wo[lw].s, d_x, dim, 0};
             a.total_rows = dim;
             a.in = d_xb;
-            const GemvShape gs = plan_gemv(dim, ahd, G, false, 1, n_cu, small_cap);
-            Ln.fn = pick<PRO_QUANT, EPI_RESID>(G, gs.RU, gs.JU, gs.FIN, gs.PF);
-            a.vr = gs.RU;
-            Ln.grid = gs.grid;
-            Ln.smem = gemv_smem_bytes(ahd, G, a.vr, false);
-            Ln.ga = a;
-            if (!Ln.fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel instantiated for this tile shape");
-            if ((rc = set_max_smem((const void*)Ln.fn, Ln.smem))) return rc;
-            if (d_stamps) { Ln.ga.stamps = d_stamps + 8 * plan.size(); Ln.ga.stamp_block = env_int("Q3_STAMP_BLOCK", 7); }
+            a.pre_q = d_xbq;
+            a.pre_s = d_xbs;
+            // quantize-in-prologue form: the long-context plan always, the short plan when attention emits no int8
+            Launch Lq = Ln;
+            GemvArgs aq = a;
+            if (const GemvCfg* cq = find_cfg(PRO_QUANT, EPI_RESID, ahd, G, env_int("Q3_CFG_WO_LONG", 0))) {
+                apply_cfg(Lq, aq, *cq, dim, n_cu);
+            } else {
+                const GemvShape gs = plan_gemv(dim, ahd, G, false, 1, n_cu, small_cap);
+                Lq.fn = pick<PRO_QUANT, EPI_RESID>(G, gs.RU, gs.JU, gs.FIN, gs.PF);
+                aq.vr = gs.RU;
+                Lq.grid = gs.grid;
+                Lq.smem = gemv_smem_bytes(ahd, G, aq.vr, false);
+            }
+            Lq.ga = aq;
+            if (!Lq.fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel instantiated for this tile shape");
+            if ((rc = set_max_smem((const void*)Lq.fn, Lq.smem))) return rc;
+            wo_long.push_back(Lq);
+            if (wo_preq) {
+                apply_cfg(Ln, a, *wo_preq, dim, n_cu);
+                Ln.ga = a;
+                if ((rc = set_max_smem((const void*)Ln.fn, Ln.smem))) return rc;
+            } else {
+                Ln = Lq;
+            }
+            if (d_stamps) { Ln.ga.stamps = d_stamps + 16 * plan.size(); Ln.ga.stamp_block = env_int("Q3_STAMP_BLOCK", 7); }
             plan.push_back(Ln);
         }
         {   // xb = RMSNorm_ffn(x); xq = quantize(xb); hb = silu(W1 xq) * (W3 xq)   qwen3.rs:159-161, layers.rs:468-475
@@ -674,15 +773,19 @@ int q3_engine::build_plan() {
             a.total_rows = 2 * H;
             a.norm_w = rms_ffn + (size_t)l * dim;
             a.in = d_x;
-            const GemvShape gs = plan_gemv(H, dim, G, true, 1, n_cu, small_cap);
-            Ln.fn = pick<PRO_NORM, EPI_SWIGLU>(G, gs.RU, gs.JU, gs.FIN, gs.PF);
-            a.vr = gs.RU;
-            Ln.grid = gs.grid;
-            Ln.smem = gemv_smem_bytes(dim, G, a.vr, true);
+            if (const GemvCfg* cfg = find_cfg(PRO_NORM, EPI_SWIGLU, dim, G, env_int("Q3_CFG_W13", 0))) {
+                apply_cfg(Ln, a, *cfg, H, n_cu);
+            } else {
+                const GemvShape gs = plan_gemv(H, dim, G, true, 1, n_cu, small_cap);
+                Ln.fn = pick<PRO_NORM, EPI_SWIGLU>(G, gs.RU, gs.JU, gs.FIN, gs.PF);
+                a.vr = gs.RU;
+                Ln.grid = gs.grid;
+                Ln.smem = gemv_smem_bytes(dim, G, a.vr, true);
+            }
             Ln.ga = a;
             if (!Ln.fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel instantiated for this tile shape");
             if ((rc = set_max_smem((const void*)Ln.fn, Ln.smem))) return rc;
-            if (d_stamps) { Ln.ga.stamps = d_stamps + 8 * plan.size(); Ln.ga.stamp_block = env_int("Q3_STAMP_BLOCK", 7); }
+            if (d_stamps) { Ln.ga.stamps = d_stamps + 16 * plan.size(); Ln.ga.stamp_block = env_int("Q3_STAMP_BLOCK", 7); }
             plan.push_back(Ln);
         }
         {   // hq = quantize(hb); x += W2 hq                                      layers.rs:478-479, qwen3.rs:175
@@ -692,15 +795,19 @@ int q3_engine::build_plan() {
             a.seg[0] = Seg{w2[lw].q, w2[lw].s, d_x, dim, 0};
             a.total_rows = dim;
             a.in = d_hb;
-            const GemvShape gs = plan_gemv(dim, H, G, false, 1, n_cu, small_cap);
-            Ln.fn = pick<PRO_QUANT, EPI_RESID>(G, gs.RU, gs.JU, gs.FIN, gs.PF);
-            a.vr = gs.RU;
-            Ln.grid = gs.grid;
-            Ln.smem = gemv_smem_bytes(H, G, a.vr, false);
+            if (const GemvCfg* cfg = find_cfg(PRO_QUANT, EPI_RESID, H, G, env_int("Q3_CFG_W2", 0))) {
+                apply_cfg(Ln, a, *cfg, dim, n_cu);
+            } else {
+                const GemvShape gs = plan_gemv(dim, H, G, false, 1, n_cu, small_cap);
+                Ln.fn = pick<PRO_QUANT, EPI_RESID>(G, gs.RU, gs.JU, gs.FIN, gs.PF);
+                a.vr = gs.RU;
+                Ln.grid = gs.grid;
+                Ln.smem = gemv_smem_bytes(H, G, a.vr, false);
+            }
             Ln.ga = a;
             if (!Ln.fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel instantiated for this tile shape");
             if ((rc = set_max_smem((const void*)Ln.fn, Ln.smem))) return rc;
-            if (d_stamps) { Ln.ga.stamps = d_stamps + 8 * plan.size(); Ln.ga.stamp_block = env_int("Q3_STAMP_BLOCK", 7); }
+            if (d_stamps) { Ln.ga.stamps = d_stamps + 16 * plan.size(); Ln.ga.stamp_block = env_int("Q3_STAMP_BLOCK", 7); }
             plan.push_back(Ln);
         }
     }
@@ -734,9 +841,12 @@ int q3_engine::build_plan() {
         plan.push_back(Ln);
     }
     // long-context plan: every attention launch becomes k_attn_scores (heads x T-chunks) + k_attn_out (heads x slices)
+    size_t wo_i = 0;
     for (const Launch& L0 : plan) {
+        if (L0.fam == F_WO) { plan_long.push_back(wo_long[wo_i++]); continue; }
         if (!L0.is_attn) { plan_long.push_back(L0); continue; }
         Launch A = L0, B = L0;
+        A.aa.xbq = B.aa.xbq = nullptr;    // the split kernels write f32 xb only; Wo quantizes in its prologue
         A.attn_kind = 1;
         A.aa.stamps = nullptr;            // developer timeline of the long plan: k_attn_out's (Q3_STAMP_SCORES=1: k_attn_scores')
         if (env_int("Q3_STAMP_SCORES", 0)) { A.aa.stamps = L0.aa.stamps; B.aa.stamps = nullptr; }
@@ -924,18 +1034,18 @@ int q3_generate_greedy(q3_engine* e, size_t first_token, size_t first_pos, size_
     clock_gettime(CLOCK_MONOTONIC, &t2);
     if (e->d_stamps) {
         const size_t nl = e->plan.size();
-        std::vector<unsigned long long> h(8 * nl);
-        HIP_TRY(hipMemcpy(h.data(), e->d_stamps, 8 * 8 * nl, hipMemcpyDeviceToHost));
-        double acc[F_COUNT][8] = {}; int cnt[F_COUNT] = {};
+        std::vector<unsigned long long> h(16 * nl);
+        HIP_TRY(hipMemcpy(h.data(), e->d_stamps, 8 * 16 * nl, hipMemcpyDeviceToHost));
+        double acc[F_COUNT][16] = {}; int cnt[F_COUNT] = {};
         for (size_t i = 0; i < nl; ++i) {
-            if (e->plan[i].is_next || h[8 * i] == 0) continue;
-            for (int k = 1; k < 7; ++k) acc[e->plan[i].fam][k] += (double)(h[8 * i + k] - h[8 * i]);
-            if (!e->plan[i].is_attn && h[8 * i + 7] > h[8 * i + 6]) acc[e->plan[i].fam][7] += (double)(h[8 * i + 7] - h[8 * i + 6]);
+            if (e->plan[i].is_next || h[16 * i] == 0) continue;
+            for (int k = 1; k < 16; ++k)
+                if (h[16 * i + k] >= h[16 * i]) acc[e->plan[i].fam][k] += (double)(h[16 * i + k] - h[16 * i]);
             cnt[e->plan[i].fam]++;
         }
         for (int f = 0; f < F_COUNT; ++f)
             if (cnt[f]) fprintf(stderr, "[q3 stamps] %-8s n=%d  issue %.0f  prologue %.0f  tile %.0f  finish %.0f  end %.0f  (s_memtime ticks after entry)\n", kFamilyNames[f], cnt[f], acc[f][1] / cnt[f], acc[f][2] / cnt[f], acc[f][3] / cnt[f], acc[f][4] / cnt[f], acc[f][5] / cnt[f]);
-        for (int f = 0; f < F_COUNT; ++f) if (cnt[f] && acc[f][7] > 0) fprintf(stderr, "[q3 stamps] %-8s exact-sum %.0f ticks\n", kFamilyNames[f], acc[f][7] / cnt[f]);
+        for (int f = 0; f < F_COUNT; ++f) if (cnt[f] && acc[f][7] > 0 && f != F_ATTN) fprintf(stderr, "[q3 stamps] %-8s prologue detail: x/sum start %.0f  sum end %.0f  quantized %.0f\n", kFamilyNames[f], acc[f][6] / cnt[f], acc[f][7] / cnt[f], acc[f][8] / cnt[f]);
         if (cnt[F_ATTN]) fprintf(stderr, "[q3 stamps] attn: issued %.0f  norm %.0f  staged %.0f  scores %.0f  softmax %.0f  vsum %.0f\n", acc[F_ATTN][1] / cnt[F_ATTN], acc[F_ATTN][2] / cnt[F_ATTN], acc[F_ATTN][3] / cnt[F_ATTN], acc[F_ATTN][4] / cnt[F_ATTN], acc[F_ATTN][5] / cnt[F_ATTN], acc[F_ATTN][6] / cnt[F_ATTN]);
     }
     if (getenv("Q3_DEBUG_TIMING"))

@@ -206,7 +206,9 @@ struct State {
 // ------------------------------------------------------------------------------------------------
 // GEMV arguments
 // ------------------------------------------------------------------------------------------------
-enum Pro : int { PRO_PREQ = 0, PRO_QUANT = 1, PRO_NORM = 2, PRO_EMBED_NORM = 3 };
+// PRO_PREQR: the producer kernel already quantized the activation (attention / SwiGLU epilogues); every lane loads its own
+// 16 bytes of xq per row chunk straight into registers -- no LDS stage, no barrier (rows of <= 4 KiB: one tile per row)
+enum Pro : int { PRO_PREQ = 0, PRO_QUANT = 1, PRO_NORM = 2, PRO_EMBED_NORM = 3, PRO_PREQR = 4 };
 enum Epi : int { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_LOGITS = 3, EPI_QKV = 4 };
 
 struct Seg {
@@ -253,8 +255,8 @@ struct GemvArgs {
 // 256 in [512, 16384] -> block length a multiple of 4; other n: blocks of 64 terms, up to 64 of them; else a plain chain).
 // Short blocks matter: the fold of a block is a dependent chain of 9-cycle adds, 16 of them for dim 1024.
 constexpr int kSpecPad = 4;       // floats of padding per block: lane j's b128 reads hit distinct banks ((blen+4)j mod 64)
-__host__ __device__ inline bool spec_ok(int n) { return n >= 512 && n <= 16384 && ((n % 256) == 0 || ((n % 64) == 0 && n <= 4096)); }
-__host__ __device__ inline int spec_blen(int n) { return (n % 256) == 0 ? n / 64 : 64; }
+__host__ __device__ constexpr bool spec_ok(int n) { return n >= 512 && n <= 16384 && ((n % 256) == 0 || ((n % 64) == 0 && n <= 4096)); }
+__host__ __device__ constexpr int spec_blen(int n) { return (n % 256) == 0 ? n / 64 : 64; }
 __host__ __device__ inline int term_floats(int n) { return n + 64 * kSpecPad; }
 
 struct GemvSmem {
@@ -266,14 +268,15 @@ struct GemvSmem {
     unsigned long long* etab;   // EPI_SWIGLU: LDS copy of the exp2 table (32 x 8 B)
 };
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~size_t(15); }
-__host__ __device__ inline size_t gemv_smem_bytes(int n, int group, int vr, bool stage_f32) {
+// waves: wavefronts per workgroup; fin: the register fold keeps the group terms out of LDS (no per-wave term rows)
+__host__ __device__ inline size_t gemv_smem_bytes(int n, int group, int vr, bool stage_f32, int waves = kWaves, bool fin = false) {
     size_t b = align16((size_t)n) + align16(4 * (size_t)(n / group));
     if (stage_f32) b += align16(4 * (size_t)term_floats(n));
-    b += align16(4 * (size_t)kWaves * vr * (n / group));
+    if (!fin) b += align16(4 * (size_t)waves * vr * (n / group));
     b += 128 * 4 + 32 * 8;
     return b;
 }
-__device__ __forceinline__ GemvSmem gemv_carve(char* base, int n, int group, int vr, bool stage_f32) {
+__device__ __forceinline__ GemvSmem gemv_carve(char* base, int n, int group, int vr, bool stage_f32, int waves = kWaves, bool fin = false) {
     GemvSmem s;
     s.xq = (int8_t*)base;
     base += align16((size_t)n);
@@ -282,20 +285,21 @@ __device__ __forceinline__ GemvSmem gemv_carve(char* base, int n, int group, int
     s.xf = (float*)base;
     if (stage_f32) base += align16(4 * (size_t)term_floats(n));
     s.term = (float*)base;
-    base += align16(4 * (size_t)kWaves * vr * (n / group));
+    if (!fin) base += align16(4 * (size_t)waves * vr * (n / group));
     s.red = (float*)base;
     s.etab = (unsigned long long*)(base + 128 * 4);
     return s;
 }
 
 // block-wide sum of one float per thread (default mode).  Deterministic order: lane tree, then waves.
+template <int NW = kWaves>
 __device__ __forceinline__ float block_sum_fast(float v, float* red) {
     v = group_sum_f32(v, 64);
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) red[wave] = v;
     __syncthreads();
     float t = red[0];
-    for (int w = 1; w < kWaves; ++w) t += red[w];
+    for (int w = 1; w < NW; ++w) t += red[w];
     __syncthreads();
     return t;
 }
@@ -703,6 +707,192 @@ __device__ __forceinline__ void gemv_prologue_finish(const GemvArgs& a, const Ge
 }
 
 // ------------------------------------------------------------------------------------------------
+// Shape-specialised prologue (round 3): contraction length N, workgroup width WGT (256 / 512 / 1024 threads) and elements
+// per thread EPT (4 / 2 / 1) are compile-time constants, group size 64.  The generic prologue above walks run-time slot
+// counts through a dozen wave-uniform branches and repeats ~150 instructions per float4 in every one of the two 256-thread
+// workgroups of a CU, one wave per SIMD pair, i.e. bound by dependent-instruction latency; here the work is straight-line,
+// one workgroup per CU spreads it over up to 16 waves (4 per SIMD: latency is hidden by the other waves), and each thread
+// handles N / WGT elements.  Same arithmetic per element (layers.rs:109-119, tensor.rs:91-119), so xq / xs are identical.
+// Thread v of pass p owns elements [(p*WGT + v)*EPT, +EPT); a quantization group is 64/EPT consecutive threads.
+// ------------------------------------------------------------------------------------------------
+template <int EPT> __device__ __forceinline__ void load_vec(const float* p, float (&d)[EPT]) {
+    if constexpr (EPT == 4) { const v4f t = *(const v4f*)p; d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; }
+    else if constexpr (EPT == 2) { const v2f t = *(const v2f*)p; d[0] = t.x; d[1] = t.y; }
+    else d[0] = *p;
+}
+template <int EPT> __device__ __forceinline__ void store_vec(float* p, const float (&d)[EPT]) {
+    if constexpr (EPT == 4) { v4f t; t.x = d[0]; t.y = d[1]; t.z = d[2]; t.w = d[3]; *(v4f*)p = t; }
+    else if constexpr (EPT == 2) { v2f t; t.x = d[0]; t.y = d[1]; *(v2f*)p = t; }
+    else *p = d[0];
+}
+// max over aligned groups of LANES (16 / 32 / 64) consecutive lanes, compile-time
+template <int LANES> __device__ __forceinline__ float group_max_c(float v) {
+    if constexpr (LANES <= 16) return group_max_f32_t<LANES>(v);
+    else return group_max_f32(v, LANES);
+}
+template <int PRO, int N, int WGT, int EPT>
+struct Pro2 {
+    static constexpr int EPP = EPT * WGT;                 // elements per pass of the whole workgroup
+    static constexpr int NP = (N + EPP - 1) / EPP;        // passes
+    static constexpr bool kFull = (N % EPP) == 0;         // every thread of every pass holds EPT live elements
+    static constexpr int GL = 64 / EPT;                   // threads per quantization group
+    static constexpr bool kNorm = (PRO == PRO_NORM || PRO == PRO_EMBED_NORM);
+    // RMSNorm: the exact sum of squares is the work of ONE wave per workgroup (wave 0).  Lane j of that wave owns block j of
+    // the vector (64 blocks of N/64 elements) and pulls it straight from global memory into registers -- no LDS staging of
+    // the squares, no barrier in front of the sum -- while the other waves wait at the barrier that publishes the factor.
+    // (r03 first cut: every wave of a 16-wave workgroup ran the sum redundantly; four waves per SIMD interleaving the same
+    // ~300-instruction loop made it issue-bound and the prologue no faster than with 4-wave workgroups.)
+    static constexpr int NQ = kNorm ? N / 256 : 1;        // float4 per lane of wave 0
+    float x[NP][EPT];
+    float w[NP][EPT];
+    v4f blk[NQ];
+};
+#ifdef Q3_DEV
+#define PRO_STAMP(a, i) stamp(a, i)
+#else
+#define PRO_STAMP(a, i) do { } while (0)
+#endif
+
+template <int PRO, int N, int WGT, int EPT>
+__device__ __forceinline__ void pro2_issue(const GemvArgs& a, Pro2<PRO, N, WGT, EPT>& pr) {
+    typedef Pro2<PRO, N, WGT, EPT> P;
+    static_assert(N % 64 == 0 && (N % EPT) == 0, "whole quantization groups");
+    static_assert(!P::kNorm || (N % 256) == 0, "64 blocks of whole float4 for the exact sum");
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tok = 0;
+    if constexpr (PRO == PRO_EMBED_NORM) tok = a.st->token;
+    if constexpr (PRO == PRO_NORM) {
+        if (wave == 0 && a.strict) {                      // oldest loads of wave 0: its block of x for the exact sum
+            const v4f* bp = (const v4f*)(a.in + (size_t)(tid & 63) * (N / 64));
+#pragma unroll
+            for (int k = 0; k < P::NQ; ++k) pr.blk[k] = bp[k];
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < P::NP; ++p) {
+        const int e0 = (p * WGT + tid) * EPT;
+        const int ec = P::kFull ? e0 : min(e0, N - EPT);          // threads past the vector re-read its tail (discarded)
+        if constexpr (PRO == PRO_NORM || PRO == PRO_QUANT) load_vec<EPT>(a.in + ec, pr.x[p]);
+        if constexpr (P::kNorm) load_vec<EPT>(a.norm_w + ec, pr.w[p]);
+    }
+    if constexpr (PRO == PRO_EMBED_NORM) {
+        // TokenEmbedding::forward over the dequantised table (layers.rs:72-76, tensor.rs:72-80)
+        const size_t row = (size_t)tok * (size_t)N;
+        if (wave == 0 && a.strict) {
+            const size_t b0 = row + (size_t)(tid & 63) * (N / 64);
+#pragma unroll
+            for (int k = 0; k < P::NQ; ++k) {
+                const size_t e = b0 + 4 * k;
+                const int packed = *(const int*)(a.emb_q + e);
+                const float sc = a.emb_s[e >> 6];
+                v4f t;
+                t.x = (float)(int8_t)(packed & 0xff) * sc;
+                t.y = (float)(int8_t)((packed >> 8) & 0xff) * sc;
+                t.z = (float)(int8_t)((packed >> 16) & 0xff) * sc;
+                t.w = (float)(int8_t)((packed >> 24) & 0xff) * sc;
+                pr.blk[k] = t;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < P::NP; ++p) {
+            const int e0 = (p * WGT + tid) * EPT;
+            const size_t e = row + (size_t)(P::kFull ? e0 : min(e0, N - EPT));
+            const float sc = a.emb_s[e >> 6];
+            int packed;
+            if constexpr (EPT == 4) packed = *(const int*)(a.emb_q + e);
+            else if constexpr (EPT == 2) packed = *(const short*)(a.emb_q + e);
+            else packed = a.emb_q[e];
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) pr.x[p][k] = (float)(int8_t)((packed >> (8 * k)) & 0xff) * sc;
+        }
+    }
+}
+
+template <int PRO, int N, int WGT, int EPT>
+__device__ __forceinline__ void pro2_finish(const GemvArgs& a, const GemvSmem& sm, Pro2<PRO, N, WGT, EPT>& pr) {
+    typedef Pro2<PRO, N, WGT, EPT> P;
+    constexpr int WAVES = WGT / 64;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (P::kNorm) {
+        // x -> RMSNorm (layers.rs:109-119)
+        float f;
+        if (a.strict) {
+            if (wave == 0) {
+                __builtin_amdgcn_s_setprio(3);
+                PRO_STAMP(a, 6);
+                float tot = 0.0f;
+#pragma unroll
+                for (int k = 0; k < P::NQ; ++k) {
+                    v4f q = pr.blk[k];
+                    q.x = q.x * q.x; q.y = q.y * q.y; q.z = q.z * q.z; q.w = q.w * q.w;      // layers.rs:113
+                    pr.blk[k] = q;
+                    tot += (q.x + q.y) + (q.z + q.w);                                        // a guess only: any order
+                }
+                const float ss = spec_sum_lanes(tot, 64, [&](float s0) {
+#pragma unroll
+                    for (int k = 0; k < P::NQ; ++k) s0 = chain4(s0, pr.blk[k]);
+                    return s0;
+                });
+                PRO_STAMP(a, 7);
+                const float fw = 1.0f / sqrtf(ss / (float)N + kEps);
+                if ((tid & 63) == 0) sm.red[0] = fw;
+                __builtin_amdgcn_s_setprio(0);
+            }
+            __syncthreads();
+            f = sm.red[0];
+        } else {
+            float part = 0.0f;
+#pragma unroll
+            for (int p = 0; p < P::NP; ++p) {
+                const bool live = P::kFull || (p * WGT + tid) * EPT < N;
+                float p4 = 0.0f;
+#pragma unroll
+                for (int k = 0; k < EPT; ++k) p4 = p4 + pr.x[p][k] * pr.x[p][k];
+                if (live) part = part + p4;
+            }
+            const float ss = block_sum_fast<WAVES>(part, sm.red);
+            f = 1.0f / sqrtf(ss / (float)N + kEps);
+        }
+#pragma unroll
+        for (int p = 0; p < P::NP; ++p) {
+            const int e0 = (p * WGT + tid) * EPT;
+            const bool live = P::kFull || e0 < N;
+            if (PRO == PRO_EMBED_NORM && live && blockIdx.x == 0) store_vec<EPT>(a.x_out + e0, pr.x[p]);
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) pr.x[p][k] = pr.w[p][k] * (f * pr.x[p][k]);       // layers.rs:117  w * (factor * x)
+            if (live && a.tap_out != nullptr && blockIdx.x == 0) store_vec<EPT>(a.tap_out + e0, pr.x[p]);
+        }
+    }
+    // quantize (tensor.rs:91-119): group max over the 64/EPT threads of a group, IEEE divisions, round half away
+#pragma unroll
+    for (int p = 0; p < P::NP; ++p) {
+        const int v = p * WGT + tid, e0 = v * EPT;
+        const bool live = P::kFull || e0 < N;
+        float m = 0.0f;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) m = fmaxf(m, fabsf(pr.x[p][k]));
+        if (!live) m = 0.0f;
+        m = group_max_c<P::GL>(m);
+        const float scale = m / 127.0f;
+        if (live) {
+            int packed = 0;
+            if (scale != 0.0f) {
+#pragma unroll
+                for (int k = 0; k < EPT; ++k) packed |= (quant_round_i8(pr.x[p][k] / scale) & 0xff) << (8 * k);
+            }
+            if constexpr (EPT == 4) ((int*)sm.xq)[v] = packed;
+            else if constexpr (EPT == 2) ((short*)sm.xq)[v] = (short)packed;
+            else sm.xq[v] = (int8_t)packed;
+            if ((v & (P::GL - 1)) == 0) sm.xs[v / P::GL] = scale;
+        }
+    }
+    PRO_STAMP(a, 8);
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
 // GEMV body.  A "unit" is one wavefront-load: 64 lanes x 16 B = 1 KiB of one weight row (chunk j of the
 // row).  Lane l owns bytes [16(l+64j), +16): LPG = G/16 adjacent lanes share a quantization group.
 // A tile = RU rows x JU chunks (RU*JU <= 8 units) is loaded into registers in one go; tiles are
@@ -730,6 +920,7 @@ struct RowSrc {
     int hu;
     int cnt;
     int row0;            // row index (within segment) of the batch's first row
+    int ops;             // EPI_QKV: floats per position of the destination (KV cache row stride), else 0
     float resid;         // EPI_RESID: x[row] of this lane's row, requested together with the batch's first tile
 };
 
@@ -769,8 +960,15 @@ __device__ __forceinline__ float ordered_row_sum(const float* t, int ng) {
 // PF = 1 (streaming launches where every wave has at least two tiles): the SECOND tile is requested before the activation
 // prologue as well, so 2 x 8 KiB per wave (32 MB chip-wide at 2 workgroups per CU) are in flight while the norm / exact
 // sum / quantize run -- the prologue no longer opens a bubble in the HBM stream.
-template <int PRO, int EPI, int LPG_T, int RU, int JU, int FIN = 0, int PF = 0>
-__global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
+// N_T > 0 (round 3): contraction length, workgroup width WGT and elements per prologue thread EPT are compile-time (group
+// 64, register fold): the prologue is pro2_*, every index derived from n folds, and one workgroup of up to 16 waves per CU
+// replaces two of four.  N_T == 0: the generic run-time-n kernel (any group size; 256 threads).
+template <int PRO, int EPI, int LPG_T, int RU, int JU, int FIN = 0, int PF = 0, int N_T = 0, int WGT = kWG, int EPT = 4>
+__global__ __launch_bounds__(WGT) void k_gemv(const GemvArgs a) {
+    static_assert(N_T > 0 || (WGT == kWG && EPT == 4), "the generic prologue is written for 256 threads");
+    static_assert(N_T == 0 || (LPG_T == 4 && FIN == 1), "specialised shapes: group 64, register fold");
+    static_assert(PRO != PRO_PREQR || (N_T > 0 && (N_T + 1023) / 1024 == JU), "register-direct xq: one tile per row");
+    constexpr int WAVES = WGT / 64;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     stamp(a, 0);
     Q3_PIN_S(a.in); Q3_PIN_S(a.n); Q3_PIN_S(a.group); Q3_PIN_S(a.total_rows); Q3_PIN_S(a.strict);
@@ -778,7 +976,7 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
     if constexpr (PRO == PRO_NORM || PRO == PRO_EMBED_NORM) Q3_PIN_S(a.norm_w);
     if constexpr (PRO == PRO_EMBED_NORM) { Q3_PIN_S(a.emb_q); Q3_PIN_S(a.emb_s); Q3_PIN_S(a.x_out); }
     if constexpr (PRO == PRO_EMBED_NORM || EPI == EPI_QKV) Q3_PIN_S(a.st);
-    if constexpr (PRO == PRO_PREQ) { Q3_PIN_S(a.pre_q); Q3_PIN_S(a.pre_s); }
+    if constexpr (PRO == PRO_PREQ || PRO == PRO_PREQR) { Q3_PIN_S(a.pre_q); Q3_PIN_S(a.pre_s); }
     if constexpr (EPI == EPI_SWIGLU) { Q3_PIN_S(a.seg[1].wq); Q3_PIN_S(a.seg[1].ws); }
     if constexpr (EPI == EPI_QKV) {
         Q3_PIN_S(a.seg[0].out_pos_stride); Q3_PIN_S(a.seg[1].rows); Q3_PIN_S(a.seg[2].rows);
@@ -788,34 +986,53 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
     }
     if constexpr (EPI == EPI_LOGITS) Q3_PIN_S(a.argmax_slots);
     // the activation / norm-weight loads go out before anything else is computed (they are the critical path)
-    ProRegs<PRO> pr;
+    constexpr bool kSpec = N_T > 0;
+    constexpr bool kPro2 = kSpec && (PRO == PRO_QUANT || PRO == PRO_NORM || PRO == PRO_EMBED_NORM);
+    ProRegs<kPro2 || PRO == PRO_PREQR ? PRO_PREQ : PRO> pr;                          // generic prologue registers (empty for PREQ)
+    Pro2<PRO, kPro2 ? N_T : 64, kPro2 ? WGT : 64, kPro2 ? EPT : 4> pr2;              // specialised prologue registers
     unsigned long long etv = 0ull;
     if (EPI == EPI_SWIGLU && threadIdx.x < 32) etv = kExp2Tab[threadIdx.x];   // oldest load: retires first (vmcnt is in order)
-    gemv_prologue_issue<PRO>(a, pr);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    v4i xr[PRO == PRO_PREQR ? JU : 1];        // PRO_PREQR: this lane's 16 bytes of xq of every chunk of a row, and their
+    float xsr[PRO == PRO_PREQR ? JU : 1];     // group scales
+    if constexpr (PRO == PRO_PREQR) {
+#pragma unroll
+        for (int j = 0; j < JU; ++j) {
+            const int c = min(lane + 64 * j, (N_T >> 4) - 1);
+            xr[j] = ((const v4i*)a.pre_q)[c];
+            xsr[j] = a.pre_s[c >> 2];
+        }
+    } else if constexpr (kPro2) pro2_issue<PRO, N_T, WGT, EPT>(a, pr2);
+    else gemv_prologue_issue<PRO>(a, pr);
+    // EPI_QKV: the position is REQUESTED here (behind the activation, ahead of the weights) and only turned into a scalar
+    // after the prologue -- a v_readfirstlane right here made hipcc wait for every load above before the first weight tile
+    // was requested (r02 disassembly: s_waitcnt vmcnt(0) in front of the tile loads)
+    int pos_v = 0;
+    if constexpr (EPI == EPI_QKV) pos_v = a.st->pos;
     __builtin_amdgcn_sched_barrier(0);        // (pin the issue order: vmcnt retires in order)
     constexpr bool kStage = (PRO == PRO_NORM || PRO == PRO_EMBED_NORM);
     constexpr int HU = (EPI == EPI_SWIGLU) ? (RU / 2) : RU;   // rows per run
     static_assert(EPI != EPI_SWIGLU || RU >= 2, "SwiGLU tiles hold a w1 and a w3 row");
-    const GemvSmem sm = gemv_carve(smem_raw, a.n, a.group, RU, kStage);
+    const int n = kSpec ? N_T : a.n, G = kSpec ? 64 : a.group;
+    const GemvSmem sm = gemv_carve(smem_raw, n, G, RU, kStage && !kSpec, WAVES, FIN != 0);
 
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int n = a.n, G = a.group;
     const int lpg_shift = (LPG_T > 0) ? __builtin_ctz(LPG_T) : __builtin_ctz(G >> 4);   // G is a power of two >= 16
     const int lpg = 1 << lpg_shift;
     const int ng = n / G;
     const int nchunks = n >> 4;
     const int nj = (n + 1023) >> 10;
     const int njt = (nj + JU - 1) / JU;            // tiles per row batch
-    float* term = sm.term + wave * RU * ng;
-    const int gw = blockIdx.x * kWaves + wave;
-    const int nwaves = gridDim.x * kWaves;
+    float* term = sm.term + (FIN != 0 ? 0 : wave * RU * ng);
+    // batch b of the launch belongs to wave b % nwaves.  Specialised shapes number the waves workgroup-minor, so a launch
+    // with fewer row batches than waves (Wo / W2 of the small models under 16-wave workgroups) still puts rows on every CU;
+    // the surplus waves only help with the prologue.
+    const int gw = kSpec ? wave * (int)gridDim.x + (int)blockIdx.x : (int)blockIdx.x * WAVES + wave;
+    const int nwaves = gridDim.x * WAVES;
     const int units = (EPI == EPI_SWIGLU) ? a.seg[0].rows : a.total_rows;   // rows (or hidden units)
     //   // rows (or hidden units)
     const int nb = (units + HU - 1) / HU;
-    // (readfirstlane: the value is wave-uniform, but a vector load lands in a VGPR and every address / branch derived from it
-    // would be computed per lane)
-    const int pos = (EPI == EPI_QKV) ? __builtin_amdgcn_readfirstlane(a.st->pos) : 0;
+    int pos = 0;                                     // EPI_QKV: set behind the prologue (see pos_v)
 
     // QKV: segments 1,2 are addressed as byte deltas from segment 0 and blended with 0/1 arithmetic (a
     // select between pointers loaded from the kernarg segment gets folded by LLVM into a VECTOR load of
@@ -851,7 +1068,8 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
             rs.w[1] = rs.w[0];
             rs.s[1] = rs.s[0];
         }
-        rs.out = out + l0 + ((EPI == EPI_QKV) ? (size_t)pos * ops : 0);
+        rs.out = out + l0;
+        rs.ops = ops;
         rs.resid = (EPI == EPI_RESID) ? rs.out[min(lane, rs.cnt - 1)] : 0.0f;
         return rs;
     };
@@ -904,8 +1122,10 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
                 const int c = lane + 64 * (jt * JU + j);
                 const bool cok = chunks_fit || c < nchunks;
                 const int cc = chunks_fit ? c : min(c, nchunks - 1);
-                const v4i xv = ((const v4i*)sm.xq)[cc];
-                const float xsc = sm.xs[cc >> 2];
+                v4i xv;
+                float xsc;
+                if constexpr (PRO == PRO_PREQR) { xv = xr[j]; xsc = xsr[j]; }
+                else { xv = ((const v4i*)sm.xq)[cc]; xsc = sm.xs[cc >> 2]; }
                 float t[RU], acc[RU];
 #pragma unroll
                 for (int r = 0; r < RU; ++r) {
@@ -964,19 +1184,27 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
         if (lane < rs.cnt) {
             float acc, up = 0.0f;
             if constexpr (FIN != 0) {
-                acc = racc[0];
+                // row r's sum (wave-uniform) goes to lane r.  Each value passes through an opaque scalar: LLVM otherwise turns
+                // the select chain into a lane-indexed read of racc[], i.e. a private (scratch) array (r02: 32-48 B/lane)
+                auto pick = [&](int base) {
+                    float v = 0.0f;
 #pragma unroll
-                for (int r = 1; r < HU; ++r) acc = (lane == r) ? racc[r] : acc;
-                if constexpr (EPI == EPI_SWIGLU) {
-                    up = racc[HU];
-#pragma unroll
-                    for (int r = 1; r < HU; ++r) up = (lane == r) ? racc[HU + r] : up;
-                }
+                    for (int r = 0; r < HU; ++r) {
+                        int sv = __builtin_amdgcn_readfirstlane(__float_as_int(racc[base + r]));
+                        asm volatile("" : "+s"(sv));
+                        v = (r == 0 || lane == r) ? __int_as_float(sv) : v;
+                    }
+                    return v;
+                };
+                acc = pick(0);
+                if constexpr (EPI == EPI_SWIGLU) up = pick(HU);
             } else {
                 acc = Q3_DEV_ABLATE(a, 4) ? term[lane * ng] : ordered_row_sum(term + lane * ng, ng);
             }
-            if (EPI == EPI_STORE || EPI == EPI_QKV) {
+            if (EPI == EPI_STORE) {
                 rs.out[lane] = acc;
+            } else if (EPI == EPI_QKV) {
+                rs.out[(size_t)pos * rs.ops + lane] = acc;    // V rows go straight into the cache row of this position
             } else if (EPI == EPI_RESID) {
                 rs.out[lane] = rs.resid + acc;          // ResidualConnection::forward, layers.rs:249-259
             } else if (EPI == EPI_SWIGLU) {
@@ -1020,8 +1248,11 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
         __syncthreads();
     } else {
     if (EPI == EPI_SWIGLU && threadIdx.x < 32) sm.etab[threadIdx.x] = etv;   // visible after the prologue's barrier
-    gemv_prologue_finish<PRO, LPG_T>(a, sm, pr);     // ... and norm + quantize run under the weight loads
+    if constexpr (PRO == PRO_PREQR) { if (EPI == EPI_SWIGLU) __syncthreads(); }
+    else if constexpr (kPro2) pro2_finish<PRO, N_T, WGT, EPT>(a, sm, pr2);
+    else gemv_prologue_finish<PRO, LPG_T>(a, sm, pr);     // ... and norm + quantize run under the weight loads
     }
+    if constexpr (EPI == EPI_QKV) pos = __builtin_amdgcn_readfirstlane(pos_v);   // older than every weight load: a counted wait
     stamp(a, 2);
     if (any && !Q3_DEV_ABLATE(a, 2)) {
         bool enter_mid = false;               // PF: the loop is entered at its midpoint (current tile in TB)
@@ -1081,7 +1312,7 @@ __global__ __launch_bounds__(kWG) void k_gemv(const GemvArgs a) {
         __syncthreads();
         if (threadIdx.x == 0) {
             unsigned long long b = wred[0];
-            for (int w = 1; w < kWaves; ++w) b = wred[w] > b ? wred[w] : b;
+            for (int w = 1; w < WAVES; ++w) b = wred[w] > b ? wred[w] : b;
             a.argmax_slots[blockIdx.x] = b;
         }
     }
@@ -1125,6 +1356,11 @@ struct AttnArgs {
     // by the scores kernel so that k_attn_out finds the row maximum without a block-wide reduction (nullptr: not available)
     float* att_cmax;
     int cmax_stride;
+    // single-stream short-context kernel: also emit xb quantized (tensor.rs:91-119, groups of `xb_group` <= 64 elements, plain
+    // order) so that the Wo launch starts from int8 + scales (PRO_PREQR) instead of re-quantizing in every workgroup
+    int8_t* xbq;
+    float* xbs;
+    int xb_group;
 };
 
 // LDS plan of k_attn (floats): q_s[hd] k_s[hd] raw[2hd] sq[2hd] opart[kWaves*hd] red[64] att[att_lds]
@@ -1597,6 +1833,15 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
             if (32 * (c + 1) < np) fold_chunk(vv[1], c + 1);
         }
         a.xb[(size_t)h * HD + e] = o;
+        if (a.xbq != nullptr) {
+            // qwen3.rs:152  quantize(xb): this wave's 64 outputs are whole quantization groups (xb_group divides 64)
+            const float m = group_max_f32(fabsf(o), a.xb_group);
+            const float scale = m / 127.0f;
+            const int qv = (scale != 0.0f) ? quant_round_i8(o / scale) : 0;
+            const int idx = h * HD + e;
+            a.xbq[idx] = (int8_t)qv;
+            if ((idx & (a.xb_group - 1)) == 0) a.xbs[idx / a.xb_group] = scale;
+        }
         ATTS_STAMP(6, kWG - 64);
         return;
     }
