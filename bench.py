@@ -285,7 +285,7 @@ def worker_main(args):
 def cpu_baseline(path, ctx, first_tok, first_pos, gpu_tokens, max_tokens=128, budget_s=25.0, one_thread_budget_s=10.0):
     """Oracle leg (test infrastructure used as the reported CPU baseline, kind "port").  Sample = the first
     min(len(gpu_tokens), max_tokens) generated tokens of the same run (128 tokens), bounded by budget_s.
-    Thread count: a sweep timed on 8 tokens per candidate, best of 3 repetitions each (a token is ~200 OpenMP
+    Thread count: a sweep timed on 8 tokens per candidate, median of 3 repetitions each (a token is ~200 OpenMP
     fork-joins, so "all cores" loses to fewer threads on big hosts and a 2-token sweep was noise: VERDICT r2); the whole
     sweep table goes into the JSON so a run-to-run spread is visible.  The OpenMP runtime is pinned
     (OMP_PROC_BIND=close, OMP_PLACES=cores) and keeps its workers spinning between the parallel regions
@@ -297,7 +297,9 @@ def cpu_baseline(path, ctx, first_tok, first_pos, gpu_tokens, max_tokens=128, bu
     m.forward(first_tok, first_pos)           # untimed: page-in of the mmap'd checkpoint
     ncpu = os.cpu_count() or 1
     want = min(len(gpu_tokens), max_tokens, ctx - first_pos)
-    cands = sorted({c for c in (4, 8, 16, 32, 64, 128, ncpu) if c <= ncpu})
+    # more threads than ~64 never won on the 128-core / 256-thread GPU hosts, and with spinning workers
+    # (OMP_WAIT_POLICY=active) an oversubscribed team takes minutes per token: the sweep stops at 64
+    cands = sorted({c for c in (4, 8, 16, 32, 64) if c <= ncpu})
 
     def run(threads, limit, budget):
         co.set_num_threads(threads)
@@ -319,8 +321,9 @@ def cpu_baseline(path, ctx, first_tok, first_pos, gpu_tokens, max_tokens=128, bu
                 break
             tk, dt = run(c, sweep_tokens, 5.0)
             rates.append(len(tk) / dt)
-        sweep.append({"threads": c, "tok_s_best": round(max(rates), 2), "tok_s_all": [round(r, 2) for r in rates]})
-    best_c = max(sweep, key=lambda r: r["tok_s_best"])["threads"]
+        rates_s = sorted(rates)
+        sweep.append({"threads": c, "tok_s_median": round(rates_s[len(rates_s) // 2], 2), "tok_s_all": [round(r, 2) for r in rates]})
+    best_c = max(sweep, key=lambda r: r["tok_s_median"])["threads"]     # the median: a count that is fast once and slow twice loses
 
     toks, dt = run(best_c, want, budget_s)
     toks1, dt1 = run(1, want, one_thread_budget_s)
@@ -329,7 +332,7 @@ def cpu_baseline(path, ctx, first_tok, first_pos, gpu_tokens, max_tokens=128, bu
     match = toks == gpu[:len(toks)] and toks1 == gpu[:len(toks1)] and len(toks) > 0
     return {"value": len(toks) / dt, "unit": "tokens/s", "cores": best_c, "kind": "port",
             "sample": f"first {len(toks)} generated tokens of the same run ({dt:.1f} s) on {best_c} of {ncpu} host threads "
-                      f"(winner of the sweep below: {sweep_tokens} tokens per candidate, best of 3); C restatement of the Rust CPU "
+                      f"(winner of the sweep below: {sweep_tokens} tokens per candidate, median of 3); C restatement of the Rust CPU "
                       f"path (no rustc in the image), OpenMP over rows/heads like rayon, threads pinned "
                       f"(OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}, OMP_PLACES={os.environ.get('OMP_PLACES')}, "
                       f"OMP_WAIT_POLICY={os.environ.get('OMP_WAIT_POLICY')})",

@@ -190,24 +190,30 @@ const GemvCfg kGemvCfgs[] = {
     // --- QKV: RMSNorm_att + quantize + wq|wk|wv
     Q3_CFG_NORM_QKV(1024, 1024, 1, 1, 1, 0), Q3_CFG_NORM_QKV(1024, 1024, 4, 1, 1, 0), Q3_CFG_NORM_QKV(1024, 512, 2, 2, 1, 0),
     Q3_CFG_NORM_QKV(1024, 256, 4, 2, 1, 0),
-    Q3_CFG_NORM_QKV(2560, 1024, 4, 2, 3, 0), Q3_CFG_NORM_QKV(2560, 512, 4, 2, 3, 0),
-    Q3_CFG_NORM_QKV(4096, 1024, 4, 2, 4, 0), Q3_CFG_NORM_QKV(4096, 512, 4, 2, 4, 0), Q3_CFG_NORM_QKV(4096, 1024, 4, 1, 4, 0),
+    Q3_CFG_NORM_QKV(2560, 1024, 4, 1, 3, 0), Q3_CFG_NORM_QKV(2560, 1024, 4, 1, 3, 1), Q3_CFG_NORM_QKV(2560, 1024, 4, 2, 3, 0),
+    Q3_CFG_NORM_QKV(4096, 1024, 4, 1, 4, 0), Q3_CFG_NORM_QKV(4096, 1024, 4, 1, 4, 1), Q3_CFG_NORM_QKV(4096, 1024, 4, 2, 4, 0),
     // --- W1|W3 + SwiGLU
     Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 1024, 1, 2, 1, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 1024, 4, 2, 1, 0),
     Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 512, 2, 4, 1, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 256, 4, 4, 1, 0),
-    Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 1024, 4, 2, 3, 1), Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 512, 4, 2, 3, 1),
-    Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 1024, 4, 2, 4, 1), Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 512, 4, 2, 4, 1),
+    Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 1024, 4, 2, 3, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 512, 4, 2, 3, 1),
+    Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 512, 4, 2, 3, 0),
+    Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 1024, 4, 2, 4, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 512, 4, 2, 4, 1),
+    Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 512, 4, 2, 4, 0),
     // --- Wo behind the short-context attention kernel (xb arrives quantized): register-direct activation
     Q3_CFG(PRO_PREQR, EPI_RESID, 2048, 256, 4, 1, 2, 0), Q3_CFG(PRO_PREQR, EPI_RESID, 2048, 512, 4, 1, 2, 0),
     Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 256, 4, 1, 4, 0), Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 256, 4, 2, 4, 0),
     Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 512, 4, 1, 4, 0),
     // --- quantize + W2 (and Wo of the long-context plan)
-    Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 1024, 4, 1, 3, 0), Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 512, 4, 1, 3, 0),
-    Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 256, 4, 1, 3, 0),
+    Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 512, 4, 1, 3, 0), Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 256, 4, 1, 3, 0),
+    Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 1024, 4, 1, 3, 0),
     Q3_CFG(PRO_QUANT, EPI_RESID, 9728, 1024, 4, 1, 2, 1), Q3_CFG(PRO_QUANT, EPI_RESID, 9728, 512, 4, 1, 2, 1),
     Q3_CFG(PRO_QUANT, EPI_RESID, 12288, 1024, 4, 1, 4, 1), Q3_CFG(PRO_QUANT, EPI_RESID, 12288, 512, 4, 1, 4, 1),
     Q3_CFG(PRO_QUANT, EPI_RESID, 2048, 512, 4, 1, 2, 0), Q3_CFG(PRO_QUANT, EPI_RESID, 2048, 256, 4, 1, 2, 0),
     Q3_CFG(PRO_QUANT, EPI_RESID, 4096, 1024, 4, 1, 4, 0), Q3_CFG(PRO_QUANT, EPI_RESID, 4096, 512, 4, 1, 4, 0),
+    // --- final RMSNorm + classifier (streaming: two tiles requested before the prologue)
+    Q3_CFG(PRO_NORM, EPI_LOGITS, 1024, 256, 4, 8, 1, 1), Q3_CFG(PRO_NORM, EPI_LOGITS, 1024, 512, 4, 8, 1, 1),
+    Q3_CFG(PRO_NORM, EPI_LOGITS, 2560, 256, 4, 2, 3, 1), Q3_CFG(PRO_NORM, EPI_LOGITS, 2560, 512, 4, 2, 3, 1),
+    Q3_CFG(PRO_NORM, EPI_LOGITS, 4096, 256, 4, 2, 4, 1), Q3_CFG(PRO_NORM, EPI_LOGITS, 4096, 512, 4, 2, 4, 1),
 };
 const GemvCfg* find_cfg(int pro, int epi, int n, int G, int which) {
     if (G != 64 || which < 0) return nullptr;
@@ -258,6 +264,7 @@ struct q3_engine {
     int out_cap = 0;
     unsigned long long* d_stamps = nullptr;   // developer timeline (Q3_STAMPS=1)
     unsigned long long* d_argmax_slots = nullptr;
+    unsigned long long* d_next_cell = nullptr;   // {argmax cell, ticket counter} of the classifier launch with k_next folded in
     int n_argmax_slots = 0;
     // pinned host staging
     float* h_logits = nullptr;
@@ -346,7 +353,14 @@ static void launch_attn_scores(const AttnArgs& a, int kvm, unsigned gx, unsigned
     else hipLaunchKernelGGL(k_attn_scores, dim3(gx, gy), dim3(kWG), smem, st, a);
 }
 
-void launch_one(const Launch& L, q3_engine* e) {
+// no_next: the classifier launch without the folded bookkeeping (q3_profile replays launches without advancing the state)
+void launch_one(const Launch& L, q3_engine* e, bool no_next = false) {
+    if (no_next && L.fam == F_LMHEAD && L.ga.next_cell != nullptr) {
+        Launch M = L;
+        M.ga.next_cell = nullptr;
+        hipLaunchKernelGGL(M.fn, dim3(M.grid), dim3(M.block), M.smem, e->stream, M.ga);
+        return;
+    }
     if (L.is_attn) {
         if (L.attn_kind == 1) launch_attn_scores(L.aa, L.scores_kvm, L.grid, L.grid_y, L.smem, e->stream);
         else if (L.attn_kind == 2) launch_attn_out(L.aa, L.grid, L.grid_y, L.smem, e->stream);
@@ -436,7 +450,9 @@ void apply_cfg(Launch& Ln, GemvArgs& a, const GemvCfg& c, int units, int n_cu) {
     Ln.fn = c.fn;
     Ln.grid = (unsigned)grid;
     Ln.block = (unsigned)c.wgt;
-    Ln.smem = gemv_smem_bytes(c.n, 64, c.ru, false, waves, true);      // (no f32 staging: wave 0 sums out of registers)
+    // f32 staging only for the long vectors' block transpose (wave 0 sums out of registers)
+    const bool stage = (c.pro == PRO_NORM || c.pro == PRO_EMBED_NORM) && c.n > 1024;
+    Ln.smem = gemv_smem_bytes(c.n, 64, c.ru, stage, waves, true);
 }
 
 }  // namespace
@@ -447,7 +463,7 @@ void q3_engine::release() {
     if (graph) (void)hipGraphDestroy(graph);
     if (graph_long_exec) (void)hipGraphExecDestroy(graph_long_exec);
     if (graph_long) (void)hipGraphDestroy(graph_long);
-    void* dptrs[] = {d_xbq, d_xbs, d_sampler, d_probs, d_sp, d_keys, d_prompt, d_att_priv, d_argmax_slots, d_stamps, d_blob, d_x, d_q, d_kraw, d_xb, d_hb, d_logits, d_tap, d_key, d_value, d_rope, d_att, d_state, d_out_tokens};
+    void* dptrs[] = {d_next_cell, d_xbq, d_xbs, d_sampler, d_probs, d_sp, d_keys, d_prompt, d_att_priv, d_argmax_slots, d_stamps, d_blob, d_x, d_q, d_kraw, d_xb, d_hb, d_logits, d_tap, d_key, d_value, d_rope, d_att, d_state, d_out_tokens};
     for (void* p : dptrs)
         if (p) (void)hipFree(p);
     if (h_logits) (void)hipHostFree(h_logits);
@@ -675,6 +691,7 @@ int q3_engine::build_plan() {
                 a.x_out = d_x;
             }
             if (cfg) {
+                a.xfirst = env_int("Q3_XFIRST", dim >= 2048 ? 1 : 0);
                 apply_cfg(Ln, a, *cfg, a.total_rows, n_cu);
             } else {
                 const GemvShape gs = plan_gemv(a.total_rows, dim, G, false, hd, n_cu, small_cap);
@@ -820,21 +837,40 @@ int q3_engine::build_plan() {
         a.norm_w = rms_final;
         a.in = d_x;
         a.tap_out = d_tap;
-        const GemvShape gs = plan_gemv(V, dim, G, false, 1, n_cu, big_cap, false);
+        GemvShape gs = plan_gemv(V, dim, G, false, 1, n_cu, big_cap, false);
+        const GemvCfg* lcfg = find_cfg(PRO_NORM, EPI_LOGITS, dim, G, env_int("Q3_CFG_LMHEAD", 1));
+        if (lcfg) {
+            apply_cfg(Ln, a, *lcfg, V, n_cu);
+            // streaming launch: cap the grid at the resident set (grid-stride over the row batches)
+            const unsigned cap = (unsigned)(n_cu * (lcfg->wgt >= 512 ? 1 : 2));
+            if (Ln.grid > cap) Ln.grid = cap;
+            gs.grid = Ln.grid;
+        }
         n_argmax_slots = (int)gs.grid;
         HIP_TRY(hipMalloc((void**)&d_argmax_slots, 8 * (size_t)n_argmax_slots));
         HIP_TRY(hipMemset(d_argmax_slots, 0, 8 * (size_t)n_argmax_slots));
         a.argmax_slots = d_argmax_slots;
-        Ln.fn = pick<PRO_NORM, EPI_LOGITS>(G, gs.RU, gs.JU, 0, gs.PF);
-        a.vr = gs.RU;
-        Ln.grid = gs.grid;
-        Ln.smem = gemv_smem_bytes(dim, G, a.vr, true);
+        const bool fuse_next = env_int("Q3_FUSE_NEXT", 1) != 0;
+        if (fuse_next) {
+            HIP_TRY(hipMalloc((void**)&d_next_cell, 16));
+            HIP_TRY(hipMemset(d_next_cell, 0, 16));
+            a.next_cell = d_next_cell;
+            a.out_tokens = d_out_tokens;
+            a.out_cap = out_cap;
+            a.prompt = d_prompt;
+        }
+        if (!lcfg) {
+            Ln.fn = pick<PRO_NORM, EPI_LOGITS>(G, gs.RU, gs.JU, 0, gs.PF);
+            a.vr = gs.RU;
+            Ln.grid = gs.grid;
+            Ln.smem = gemv_smem_bytes(dim, G, a.vr, true);
+        }
         Ln.ga = a;
         if (!Ln.fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel instantiated for this tile shape");
         if ((rc = set_max_smem((const void*)Ln.fn, Ln.smem))) return rc;
         plan.push_back(Ln);
     }
-    {
+    if (d_next_cell == nullptr) {
         Launch Ln;
         Ln.fam = F_NEXT;
         Ln.is_next = true;
@@ -1186,11 +1222,11 @@ int q3_profile(q3_engine* e, size_t token, size_t pos, int reps, float* ms, int3
         // one full forward first so every family runs on live data, then each family's launches back to back
         // between ONE pair of events: the average is the launch period (kernel + boundary), the same quantity
         // rocprofv3's per-dispatch durations sum to on a serialised stream.
-        for (size_t i = 0; i < nl; ++i) if (!P[i].is_next) launch_one(P[i], e);
+        for (size_t i = 0; i < nl; ++i) if (!P[i].is_next) launch_one(P[i], e, true);
         for (int f = 0; f < F_COUNT; ++f) {
             HIP_TRY(hipEventRecord(ev[2 * f], e->stream));
             for (size_t i = 0; i < nl; ++i)
-                if (P[i].fam == f) { launch_one(P[i], e); launches[f] += 1; }
+                if (P[i].fam == f) { launch_one(P[i], e, true); launches[f] += 1; }
             HIP_TRY(hipEventRecord(ev[2 * f + 1], e->stream));
         }
         HIP_TRY(hipStreamSynchronize(e->stream));

@@ -243,6 +243,16 @@ struct GemvArgs {
     float* tap_out;        // PRO_NORM: optional copy of the normalised vector (workgroup 0)
     unsigned long long* argmax_slots;  // EPI_LOGITS: one (key<<32|index) per workgroup
     int seq_len;
+    // EPI_LOGITS with the bookkeeping of k_next folded in (next_cell != nullptr): every workgroup max-reduces its key into
+    // next_cell[0] and takes a ticket from next_cell[1]; the last arriver consumes the cell and advances the state
+    unsigned long long* next_cell;
+    int32_t* out_tokens;
+    int out_cap;
+    const int32_t* prompt;
+    // specialised NORM launches whose weight stream is shorter than their prologue (QKV of the 4B / 8B shapes): request the
+    // weights only after wave 0 holds its block of x -- otherwise x queues behind tens of MB of weight requests of the other
+    // workgroups and the exact sum starts ~3.5 us late (r03 stamps, 8B QKV: x after 8,955 cycles)
+    int xfirst;
 };
 
 // LDS layout of the GEMV kernels (dynamic shared memory, 16-byte aligned carve):
@@ -743,6 +753,7 @@ struct Pro2 {
     // (r03 first cut: every wave of a 16-wave workgroup ran the sum redundantly; four waves per SIMD interleaving the same
     // ~300-instruction loop made it issue-bound and the prologue no faster than with 4-wave workgroups.)
     static constexpr int NQ = kNorm ? N / 256 : 1;        // float4 per lane of wave 0
+    static constexpr bool kBlkViaLds = (PRO == PRO_NORM) && NQ > 4;   // coalesced loads + LDS transpose (see pro2_issue)
     float x[NP][EPT];
     float w[NP][EPT];
     v4f blk[NQ];
@@ -753,8 +764,9 @@ struct Pro2 {
 #define PRO_STAMP(a, i) do { } while (0)
 #endif
 
+// what: 0 = everything; 1 = only wave 0's block of x (the exact sum's operands); 2 = everything else (GemvArgs::xfirst)
 template <int PRO, int N, int WGT, int EPT>
-__device__ __forceinline__ void pro2_issue(const GemvArgs& a, Pro2<PRO, N, WGT, EPT>& pr) {
+__device__ __forceinline__ void pro2_issue(const GemvArgs& a, Pro2<PRO, N, WGT, EPT>& pr, int what = 0) {
     typedef Pro2<PRO, N, WGT, EPT> P;
     static_assert(N % 64 == 0 && (N % EPT) == 0, "whole quantization groups");
     static_assert(!P::kNorm || (N % 256) == 0, "64 blocks of whole float4 for the exact sum");
@@ -763,23 +775,34 @@ __device__ __forceinline__ void pro2_issue(const GemvArgs& a, Pro2<PRO, N, WGT, 
     int tok = 0;
     if constexpr (PRO == PRO_EMBED_NORM) tok = a.st->token;
     if constexpr (PRO == PRO_NORM) {
-        if (wave == 0 && a.strict) {                      // oldest loads of wave 0: its block of x for the exact sum
-            const v4f* bp = (const v4f*)(a.in + (size_t)(tid & 63) * (N / 64));
+        if (wave == 0 && a.strict && what != 2) {         // oldest loads of wave 0: its block of x for the exact sum
+            if constexpr (P::kBlkViaLds) {
+                // long vectors: COALESCED float4 loads (lane j, slot k <- float4 j + 64k), transposed into blocks through LDS in
+                // pro2_finish.  Lane-per-block loads touch 64 cache lines per instruction: 16 of them held the 8B shapes' sum
+                // back until ~3,000 cycles after entry (r03 stamps).
+                const v4f* bp = (const v4f*)a.in + (tid & 63);
 #pragma unroll
-            for (int k = 0; k < P::NQ; ++k) pr.blk[k] = bp[k];
+                for (int k = 0; k < P::NQ; ++k) pr.blk[k] = bp[64 * k];
+            } else {
+                const v4f* bp = (const v4f*)(a.in + (size_t)(tid & 63) * (N / 64));
+#pragma unroll
+                for (int k = 0; k < P::NQ; ++k) pr.blk[k] = bp[k];
+            }
         }
     }
+    if (what != 1) {
 #pragma unroll
-    for (int p = 0; p < P::NP; ++p) {
-        const int e0 = (p * WGT + tid) * EPT;
-        const int ec = P::kFull ? e0 : min(e0, N - EPT);          // threads past the vector re-read its tail (discarded)
-        if constexpr (PRO == PRO_NORM || PRO == PRO_QUANT) load_vec<EPT>(a.in + ec, pr.x[p]);
-        if constexpr (P::kNorm) load_vec<EPT>(a.norm_w + ec, pr.w[p]);
+        for (int p = 0; p < P::NP; ++p) {
+            const int e0 = (p * WGT + tid) * EPT;
+            const int ec = P::kFull ? e0 : min(e0, N - EPT);          // threads past the vector re-read its tail (discarded)
+            if constexpr (PRO == PRO_NORM || PRO == PRO_QUANT) load_vec<EPT>(a.in + ec, pr.x[p]);
+            if constexpr (P::kNorm) load_vec<EPT>(a.norm_w + ec, pr.w[p]);
+        }
     }
     if constexpr (PRO == PRO_EMBED_NORM) {
         // TokenEmbedding::forward over the dequantised table (layers.rs:72-76, tensor.rs:72-80)
         const size_t row = (size_t)tok * (size_t)N;
-        if (wave == 0 && a.strict) {
+        if (wave == 0 && a.strict && what != 2) {
             const size_t b0 = row + (size_t)(tid & 63) * (N / 64);
 #pragma unroll
             for (int k = 0; k < P::NQ; ++k) {
@@ -794,6 +817,7 @@ __device__ __forceinline__ void pro2_issue(const GemvArgs& a, Pro2<PRO, N, WGT, 
                 pr.blk[k] = t;
             }
         }
+        if (what != 1)
 #pragma unroll
         for (int p = 0; p < P::NP; ++p) {
             const int e0 = (p * WGT + tid) * EPT;
@@ -821,6 +845,19 @@ __device__ __forceinline__ void pro2_finish(const GemvArgs& a, const GemvSmem& s
         if (a.strict) {
             if (wave == 0) {
                 __builtin_amdgcn_s_setprio(3);
+                if constexpr (P::kBlkViaLds) {
+                    // float4 (j + 64k) of x -> LDS (blocks of N/64 floats, padded by 4 against bank conflicts) -> lane j's block
+                    constexpr int BLQ = P::NQ + 1;                                           // float4 per padded block
+                    const int lane = tid & 63;
+#pragma unroll
+                    for (int k = 0; k < P::NQ; ++k) {
+                        const int f4 = lane + 64 * k;                                        // float4 index in x
+                        ((v4f*)sm.xf)[(f4 / P::NQ) * BLQ + (f4 % P::NQ)] = pr.blk[k];
+                    }
+                    wave_lds_sync();
+#pragma unroll
+                    for (int k = 0; k < P::NQ; ++k) pr.blk[k] = ((const v4f*)sm.xf)[lane * BLQ + k];
+                }
                 PRO_STAMP(a, 6);
                 float tot = 0.0f;
 #pragma unroll
@@ -984,7 +1021,7 @@ __global__ __launch_bounds__(WGT) void k_gemv(const GemvArgs a) {
         Q3_PIN_S(a.qkv_dw[0]); Q3_PIN_S(a.qkv_dw[1]); Q3_PIN_S(a.qkv_ds[0]); Q3_PIN_S(a.qkv_ds[1]);
         Q3_PIN_S(a.qkv_do[0]); Q3_PIN_S(a.qkv_do[1]);
     }
-    if constexpr (EPI == EPI_LOGITS) Q3_PIN_S(a.argmax_slots);
+    if constexpr (EPI == EPI_LOGITS) { Q3_PIN_S(a.argmax_slots); Q3_PIN_S(a.next_cell); }
     // the activation / norm-weight loads go out before anything else is computed (they are the critical path)
     constexpr bool kSpec = N_T > 0;
     constexpr bool kPro2 = kSpec && (PRO == PRO_QUANT || PRO == PRO_NORM || PRO == PRO_EMBED_NORM);
@@ -1003,19 +1040,29 @@ __global__ __launch_bounds__(WGT) void k_gemv(const GemvArgs a) {
             xr[j] = ((const v4i*)a.pre_q)[c];
             xsr[j] = a.pre_s[c >> 2];
         }
-    } else if constexpr (kPro2) pro2_issue<PRO, N_T, WGT, EPT>(a, pr2);
-    else gemv_prologue_issue<PRO>(a, pr);
+    } else if constexpr (kPro2) {
+        if constexpr (PRO == PRO_NORM || PRO == PRO_EMBED_NORM) {
+            if (a.xfirst) {                   // wave-uniform: wave 0's block of x travels alone, everything else behind it
+                pro2_issue<PRO, N_T, WGT, EPT>(a, pr2, 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+                pro2_issue<PRO, N_T, WGT, EPT>(a, pr2, 2);
+            } else pro2_issue<PRO, N_T, WGT, EPT>(a, pr2, 0);
+        } else pro2_issue<PRO, N_T, WGT, EPT>(a, pr2, 0);
+    } else gemv_prologue_issue<PRO>(a, pr);
     // EPI_QKV: the position is REQUESTED here (behind the activation, ahead of the weights) and only turned into a scalar
     // after the prologue -- a v_readfirstlane right here made hipcc wait for every load above before the first weight tile
     // was requested (r02 disassembly: s_waitcnt vmcnt(0) in front of the tile loads)
     int pos_v = 0;
     if constexpr (EPI == EPI_QKV) pos_v = a.st->pos;
     __builtin_amdgcn_sched_barrier(0);        // (pin the issue order: vmcnt retires in order)
+
     constexpr bool kStage = (PRO == PRO_NORM || PRO == PRO_EMBED_NORM);
     constexpr int HU = (EPI == EPI_SWIGLU) ? (RU / 2) : RU;   // rows per run
     static_assert(EPI != EPI_SWIGLU || RU >= 2, "SwiGLU tiles hold a w1 and a w3 row");
     const int n = kSpec ? N_T : a.n, G = kSpec ? 64 : a.group;
-    const GemvSmem sm = gemv_carve(smem_raw, n, G, RU, kStage && !kSpec, WAVES, FIN != 0);
+    const GemvSmem sm = gemv_carve(smem_raw, n, G, RU, kStage && (!kSpec || n > 1024), WAVES, FIN != 0);
 
     const int lpg_shift = (LPG_T > 0) ? __builtin_ctz(LPG_T) : __builtin_ctz(G >> 4);   // G is a power of two >= 16
     const int lpg = 1 << lpg_shift;
@@ -1313,7 +1360,32 @@ __global__ __launch_bounds__(WGT) void k_gemv(const GemvArgs a) {
         if (threadIdx.x == 0) {
             unsigned long long b = wred[0];
             for (int w = 1; w < WAVES; ++w) b = wred[w] > b ? wred[w] : b;
-            a.argmax_slots[blockIdx.x] = b;
+            if (a.next_cell == nullptr) {
+                a.argmax_slots[blockIdx.x] = b;
+            } else {
+                // k_next folded into the classifier (one launch less per token).  Only device-scope atomics carry data between
+                // workgroups, so no fence is needed: the max is performed at the coherence point before its old value returns,
+                // the ticket is drawn after that (data dependency on the returned value), and the workgroup that draws the
+                // last ticket reads the cell with a device-scope atomic load.
+                State* st = a.st;
+                const unsigned long long old =
+                    __hip_atomic_fetch_max(a.next_cell, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long ticket = __hip_atomic_fetch_add(a.next_cell + 1, old == ~0ull ? 2ull : 1ull,
+                                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ticket == (unsigned long long)gridDim.x - 1) {
+                    const unsigned long long best_all = __hip_atomic_load(a.next_cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int idx = (int)(unsigned)(best_all & 0xffffffffull);
+                    const int step = st->step;
+                    if (step < a.out_cap) a.out_tokens[step] = idx;      // the sample is drawn for every forward (generation.rs:120)
+                    // chat-mode prefill (generation.rs:116-123): inside the prompt the next input is the next prompt token
+                    st->token = (step + 1 < st->prompt_len) ? a.prompt[step + 1] : idx;
+                    st->pos = st->pos + 1;
+                    st->step = step + 1;
+                    st->argmax = best_all;
+                    __hip_atomic_store(a.next_cell, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next token
+                    __hip_atomic_store(a.next_cell + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
     }
 }
@@ -1755,14 +1827,18 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
     const int kv_mul = a.n_heads / a.n_kv_heads;
     const int kvh = h / kv_mul;
     const size_t kvd = (size_t)a.n_kv_heads * HD;
-    const int pos = __builtin_amdgcn_readfirstlane(a.pos_override >= 0 ? a.pos_override : a.st->pos);   // wave-uniform -> SGPR
-    const int np = pos + 1;
+    // the position is REQUESTED first and turned into a scalar as late as each role allows: the raw q / k values and the norm
+    // weights do not depend on it, and a v_readfirstlane right here put a full memory round trip in front of every other load
+    // (r02 stamps: loads issued 2,100 cycles after entry)
+    const int pos_v = a.pos_override >= 0 ? a.pos_override : a.st->pos;
     const float* kbase = a.key_cache + (size_t)kvh * HD;
     const float* vbase = a.value_cache + (size_t)kvh * HD;
     const int t4 = 4 * lane;                              // softmax read-back: lane l looks at timesteps 4l .. 4l+3
 
     if (wave >= NSW) {
         // ================================ output waves ================================
+        const int pos = __builtin_amdgcn_readfirstlane(pos_v);   // wave-uniform -> SGPR (the V rows have slack: they are folded last)
+        const int np = pos + 1;
         const int e = 64 * (wave - NSW) + lane;           // output element of this lane
         float vv[kShortVSets][32];
         auto v_issue = [&](float (&R)[32], int c) {
@@ -1857,6 +1933,12 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
         const float* nw = is_q ? a.q_norm_w : a.k_norm_w;
         w_lo = nw[i];
         w_hi = nw[i + HALF];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int pos = __builtin_amdgcn_readfirstlane(pos_v);       // the oldest load of the wave: a counted wait
+    const int np = pos + 1;
+    if (wave < 2) {
+        const int i = min(lane, HALF - 1);
         const float* cs = a.rope + (size_t)pos * HD;      // HD/2 (cos,sin) pairs of this position
         rc = cs[2 * i];
         rs = cs[2 * i + 1];

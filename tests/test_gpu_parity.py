@@ -376,9 +376,10 @@ def test_context_beyond_lds_score_rows_vs_oracle(q3, oracle, tmp_path_factory):
             assert names == ["qkv", "attn", "wo", "w13", "w2", "lm_head", "next"]
             L = shape.n_layers
             launches = {n: k for n, _, k in prof}
-            assert launches["qkv"] == 2 * L and launches["lm_head"] == 2 and launches["next"] == 2
+            # `next`: 0 launches when the state bookkeeping is folded into the classifier launch (round 3 default), else one
+            assert launches["qkv"] == 2 * L and launches["lm_head"] == 2 and launches["next"] in (0, 2)
             assert launches["attn"] == (2 * L if pos < 256 else 4 * L)      # split plan: scores + out kernels
-            assert all(ms > 0 for _, ms, _ in prof)
+            assert all(ms > 0 for _, ms, k in prof if k > 0)
 
 
 def test_device_prefill_matches_chat_pattern(q3, oracle):

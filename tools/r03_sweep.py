@@ -13,14 +13,14 @@ ntok = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 sh = ck.SHAPES[name]
 path = f"/tmp/q3_{name}.bin"
 ck.ensure_synthetic_checkpoint(path, sh, seed=1234)
-fams = {"QKV": "qkv", "W13": "w13", "WO": "wo", "W2": "w2"}
-counts = {"QKV": 4, "W13": 4, "WO": 2, "W2": 3}
+fams = {"QKV": "qkv", "W13": "w13", "WO": "wo", "W2": "w2", "LMHEAD": "lm_head"}
+counts = {"QKV": 4, "W13": 4, "WO": 2, "W2": 3, "LMHEAD": 2}
 if os.environ.get("Q3_SWEEP"):
     counts = {kv.split(":")[0]: int(kv.split(":")[1]) for kv in os.environ["Q3_SWEEP"].split(",")}
 
 
 def run(env):
-    for k in ("Q3_CFG_QKV", "Q3_CFG_W13", "Q3_CFG_WO", "Q3_CFG_W2"):
+    for k in ("Q3_CFG_QKV", "Q3_CFG_W13", "Q3_CFG_WO", "Q3_CFG_W2", "Q3_CFG_LMHEAD"):
         os.environ.pop(k, None)
     os.environ.update(env)
     t = q3.TransformerBuilder(path).with_ctx_length(1024).with_strict(True).build()
