@@ -1,0 +1,123 @@
+// q3_gemv_inst.hip -- every instantiation of k_gemv the planner can select, in a translation unit of its own so that
+// the library builds in parallel (make -j).  q3_engine.hip reaches the kernels only through gemv_pick() / find_cfg().
+#include <hip/hip_runtime.h>
+#define Q3_GEMV_ONLY
+#include "q3_kernels.h"
+
+using namespace q3;
+typedef void (*GemvFn)(const GemvArgs);
+
+namespace {
+
+// tile shapes instantiated: group 64 (every listed model) gets the full set, other group sizes a
+// single-row-run fallback (RU = 1, or 2 for SwiGLU).  Variants (k_gemv FIN / PF): FIN = DPP-chain fold of the group terms
+// (group 64, rows a whole number of tiles), PF = second tile requested before the prologue (streaming launches).
+// Instantiated: (FIN,PF) = (0,0) everywhere; (1,0) and (1,1) for the layer kernels; (0,1) for the classifier.
+template <int PRO, int EPI, int LPG_T, int RU, int FIN = 0, int PF = 0>
+GemvFn pick_ju(int JU) {
+    if (JU == 1) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 1, FIN, PF>;
+    if (JU == 2) { if constexpr (RU <= 4) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 2, FIN, PF>; }
+    if (JU == 3) { if constexpr (RU <= 2) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 3, FIN, PF>; }
+    if (JU == 4) { if constexpr (RU <= 2) return (GemvFn)k_gemv<PRO, EPI, LPG_T, RU, 4, FIN, PF>; }
+    return nullptr;
+}
+template <int PRO, int EPI, int FIN, int PF>
+GemvFn pick_ru64(int RU, int JU) {
+    constexpr bool sw = (EPI == EPI_SWIGLU);
+    if (RU == 8) return pick_ju<PRO, EPI, 4, 8, FIN, PF>(JU);
+    if (RU == 4) return pick_ju<PRO, EPI, 4, 4, FIN, PF>(JU);
+    if (RU == 2) return pick_ju<PRO, EPI, 4, 2, FIN, PF>(JU);
+    if constexpr (!sw) { if (RU == 1) return pick_ju<PRO, EPI, 4, 1, FIN, PF>(JU); }
+    return nullptr;
+}
+template <int PRO, int EPI>
+GemvFn pick(int G, int RU, int JU, int FIN = 0, int PF = 0) {
+    constexpr bool sw = (EPI == EPI_SWIGLU);
+    if (G == 64) {
+        if constexpr (EPI == EPI_LOGITS) {
+            if (PF) return pick_ru64<PRO, EPI, 0, 1>(RU, JU);
+            return pick_ru64<PRO, EPI, 0, 0>(RU, JU);
+        } else {
+            if (FIN && PF) return pick_ru64<PRO, EPI, 1, 1>(RU, JU);
+            if (FIN) return pick_ru64<PRO, EPI, 1, 0>(RU, JU);
+            return pick_ru64<PRO, EPI, 0, 0>(RU, JU);
+        }
+    }
+    if constexpr (sw) { if (RU == 2) return pick_ju<PRO, EPI, 0, 2>(JU); }
+    else { if (RU == 1) return pick_ju<PRO, EPI, 0, 1>(JU); }
+    return nullptr;
+}
+
+}  // namespace
+
+namespace q3inst {
+struct GemvCfg { int pro, epi, n, wgt, ept, ru, ju, pf; GemvFn fn; };
+}
+using q3inst::GemvCfg;
+
+namespace {
+// ------------------------------------------------------------------------------------------------
+// Shape-specialised GEMV launches (k_gemv with N_T > 0): every (prologue, epilogue, contraction length) of the listed
+// models (0.6B dim 1024 / hidden 3072, 4B 2560 / 9728, 8B 4096 / 12288, all heads x head_dim 2048 / 4096)
+// has one or more tile / workgroup-width candidates; the first entry of a role is the default, Q3_CFG_<FAMILY>=k picks the
+// k-th (sweeps: tools/r03_cfg_sweep.sh), -1 forces the generic run-time-n kernel.  Anything not listed (test shapes,
+// other group sizes) takes the generic path.
+// ------------------------------------------------------------------------------------------------
+#define Q3_CFG(PRO, EPI, N, WGT, EPT, RU, JU, PF) \
+    {PRO, EPI, N, WGT, EPT, RU, JU, PF, (GemvFn)k_gemv<PRO, EPI, 4, RU, JU, 1, PF, N, WGT, EPT>}
+#define Q3_CFG_NORM_QKV(N, WGT, EPT, RU, JU, PF) Q3_CFG(PRO_NORM, EPI_QKV, N, WGT, EPT, RU, JU, PF), Q3_CFG(PRO_EMBED_NORM, EPI_QKV, N, WGT, EPT, RU, JU, PF)
+const GemvCfg kGemvCfgs[] = {
+    // --- QKV: RMSNorm_att + quantize + wq|wk|wv
+    Q3_CFG_NORM_QKV(1024, 1024, 1, 1, 1, 0), Q3_CFG_NORM_QKV(1024, 1024, 4, 1, 1, 0), Q3_CFG_NORM_QKV(1024, 512, 2, 2, 1, 0),
+    Q3_CFG_NORM_QKV(1024, 256, 4, 2, 1, 0),
+    Q3_CFG_NORM_QKV(2560, 1024, 4, 1, 3, 0), Q3_CFG_NORM_QKV(2560, 1024, 4, 1, 3, 1), Q3_CFG_NORM_QKV(2560, 1024, 4, 2, 3, 0),
+    Q3_CFG_NORM_QKV(4096, 1024, 4, 1, 4, 0), Q3_CFG_NORM_QKV(4096, 1024, 4, 1, 4, 1), Q3_CFG_NORM_QKV(4096, 1024, 4, 2, 4, 0),
+    // --- W1|W3 + SwiGLU
+    Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 1024, 1, 2, 1, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 1024, 4, 2, 1, 0),
+    Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 512, 2, 4, 1, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 256, 4, 4, 1, 0),
+    Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 1024, 4, 2, 3, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 512, 4, 2, 3, 1),
+    Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 512, 4, 2, 3, 0),
+    Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 1024, 4, 2, 4, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 512, 4, 2, 4, 1),
+    Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 512, 4, 2, 4, 0),
+    // --- Wo behind the short-context attention kernel (xb arrives quantized): register-direct activation
+    Q3_CFG(PRO_PREQR, EPI_RESID, 2048, 256, 4, 1, 2, 0), Q3_CFG(PRO_PREQR, EPI_RESID, 2048, 512, 4, 1, 2, 0),
+    Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 256, 4, 1, 4, 0), Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 256, 4, 2, 4, 0),
+    Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 512, 4, 1, 4, 0),
+    // --- quantize + W2 (and Wo of the long-context plan)
+    Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 512, 4, 1, 3, 0), Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 256, 4, 1, 3, 0),
+    Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 1024, 4, 1, 3, 0),
+    Q3_CFG(PRO_QUANT, EPI_RESID, 9728, 1024, 4, 1, 2, 1), Q3_CFG(PRO_QUANT, EPI_RESID, 9728, 512, 4, 1, 2, 1),
+    Q3_CFG(PRO_QUANT, EPI_RESID, 12288, 1024, 4, 1, 4, 1), Q3_CFG(PRO_QUANT, EPI_RESID, 12288, 512, 4, 1, 4, 1),
+    Q3_CFG(PRO_QUANT, EPI_RESID, 2048, 512, 4, 1, 2, 0), Q3_CFG(PRO_QUANT, EPI_RESID, 2048, 256, 4, 1, 2, 0),
+    Q3_CFG(PRO_QUANT, EPI_RESID, 4096, 1024, 4, 1, 4, 0), Q3_CFG(PRO_QUANT, EPI_RESID, 4096, 512, 4, 1, 4, 0),
+    // --- final RMSNorm + classifier (streaming: two tiles requested before the prologue)
+    Q3_CFG(PRO_NORM, EPI_LOGITS, 1024, 256, 4, 8, 1, 1), Q3_CFG(PRO_NORM, EPI_LOGITS, 1024, 512, 4, 8, 1, 1),
+    Q3_CFG(PRO_NORM, EPI_LOGITS, 2560, 256, 4, 2, 3, 1), Q3_CFG(PRO_NORM, EPI_LOGITS, 2560, 512, 4, 2, 3, 1),
+    Q3_CFG(PRO_NORM, EPI_LOGITS, 4096, 256, 4, 2, 4, 1), Q3_CFG(PRO_NORM, EPI_LOGITS, 4096, 512, 4, 2, 4, 1),
+};
+}  // namespace
+
+namespace q3inst {
+const GemvCfg* find_cfg(int pro, int epi, int n, int G, int which) {
+    if (G != 64 || which < 0) return nullptr;
+    const GemvCfg* last = nullptr;
+    for (const GemvCfg& c : kGemvCfgs)
+        if (c.pro == pro && c.epi == epi && c.n == n) {
+            last = &c;
+            if (which-- == 0) return &c;
+        }
+    return last;                     // an index past the last candidate selects the last one
+}
+
+
+// the (prologue, epilogue) pairs the engine and the operator entry points use
+GemvFn gemv_pick(int pro, int epi, int G, int RU, int JU, int FIN, int PF) {
+    if (pro == PRO_EMBED_NORM && epi == EPI_QKV) return pick<PRO_EMBED_NORM, EPI_QKV>(G, RU, JU, FIN, PF);
+    if (pro == PRO_NORM && epi == EPI_QKV) return pick<PRO_NORM, EPI_QKV>(G, RU, JU, FIN, PF);
+    if (pro == PRO_QUANT && epi == EPI_RESID) return pick<PRO_QUANT, EPI_RESID>(G, RU, JU, FIN, PF);
+    if (pro == PRO_NORM && epi == EPI_SWIGLU) return pick<PRO_NORM, EPI_SWIGLU>(G, RU, JU, FIN, PF);
+    if (pro == PRO_NORM && epi == EPI_LOGITS) return pick<PRO_NORM, EPI_LOGITS>(G, RU, JU, FIN, PF);
+    if (pro == PRO_PREQ && epi == EPI_STORE) return pick<PRO_PREQ, EPI_STORE>(G, RU, JU, FIN, PF);
+    return nullptr;
+}
+}  // namespace q3inst

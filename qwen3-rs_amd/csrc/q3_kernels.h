@@ -130,7 +130,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // f32::exp == glibc expf (sysdeps/ieee754/flt-32/e_expf.c, the exp2f_data table with N = 32):
 // exp(x) = 2^(k/N) * 2^(r/N), k = round(x*N/ln2) by the 1.5*2^52 shift, cubic in r, all in double.
 // ------------------------------------------------------------------------------------------------
-__device__ __constant__ unsigned long long kExp2Tab[32] = {
+static __device__ __constant__ unsigned long long kExp2Tab[32] = {
     0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
     0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
     0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
@@ -1283,9 +1283,11 @@ __global__ __launch_bounds__(WGT) void k_gemv(const GemvArgs a) {
     int pb = cb, pjt = 1;                     // PF: coordinates of the tile preloaded into TB
     if constexpr (PF != 0) {
         if (pjt == njt) { pjt = 0; pb = cb + nwaves; }
-        // unconditional (static load count for the prologue's vmcnt): a wave without a second tile re-reads a valid one
+        // generic kernels: unconditional (static load count for the prologue's vmcnt) -- a wave without a second tile re-reads a
+        // valid one.  Specialised shapes skip the request (wave-uniform): their launches have whole sets of waves with a
+        // single tile (QKV of the 8B shape: 6,144 rows on 4,096 waves) and the re-reads would be a third of the traffic.
         if (pjt == 0) RB = batch_rows(min(pb, nb - 1)); else RB = RA;
-        load_tile(TB, RB, pjt);
+        if (!kSpec || pb < nb) load_tile(TB, RB, pjt);
     }
     __builtin_amdgcn_sched_barrier(0);
     stamp(a, 1);
@@ -1390,6 +1392,7 @@ __global__ __launch_bounds__(WGT) void k_gemv(const GemvArgs a) {
     }
 }
 
+#ifndef Q3_GEMV_ONLY      // (q3_gemv_inst.hip compiles the GEMV kernels only)
 // ------------------------------------------------------------------------------------------------
 // Attention: QK-RMSNorm + RoPE (layers.rs:346-372) and GQA attention over cache rows 0..=pos
 // (layers.rs:374-419).  One workgroup per query head.
@@ -1867,8 +1870,10 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
         const v4f e4 = ((const v4f*)att_e)[lane];
         float sum;
         if (np <= 128) {
-            // one chain over the (zero padded) row: np adds of 10 cycles, operands streamed from LDS as float4
-            sum = seq_chain(-0.0f, (const v4f*)att_e, (np + 3) >> 2);
+            // one chain over the (zero padded) row: np adds of 10 cycles, operands streamed from LDS as float4 -- in whole
+            // batches of 8 float4 (the row is +0.0 beyond the context and s + 0.0 == s once the first exp, > 0 or +0.0, is in):
+            // the batched path of seq_chain keeps the next reads in flight, its remainder loop pays an LDS round trip per float4
+            sum = seq_chain(-0.0f, (const v4f*)att_e, (((np + 3) >> 2) + 7) & ~7);
         } else {
             const float etot = (e4.x + e4.y) + (e4.z + e4.w);
             sum = spec_sum_lanes(etot, (np + 3) >> 2, [&](float s) { return chain4(s, e4); });
@@ -2004,15 +2009,35 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
 #pragma unroll
             for (int i = 0; i < NQ4; ++i) kr[i] = ((const v4f*)k_s)[i];
         }
+        // q arrives from LDS (broadcast reads) 8 float4 at a time, the next batch requested before the current one is folded:
+        // an LDS round trip behind every float4 (r02 code: 67 waits in this loop) cost ~900 of the pass's ~2,200 cycles,
+        // the 128 dependent adds of the reference's dot (layers.rs:395-400) are the other 1,280
         float dot = -0.0f;
+        {
+            const v4f* q4 = (const v4f*)q_s;
+            v4f qa[8], qb[8];
 #pragma unroll
-        for (int i = 0; i < NQ4; ++i) {
-            const v4f qv = ((const v4f*)q_s)[i];
-            const v4f kk = kr[i];
-            float p = qv.x * kk.x; dot = dot + p;
-            p = qv.y * kk.y; dot = dot + p;
-            p = qv.z * kk.z; dot = dot + p;
-            p = qv.w * kk.w; dot = dot + p;
+            for (int u = 0; u < 8; ++u) qa[u] = q4[u];
+#pragma unroll
+            for (int b = 0; b < NQ4 / 8; ++b) {
+                if (b + 1 < NQ4 / 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) qb[u] = q4[8 * (b + 1) + u];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const v4f qv = qa[u];
+                    const v4f kk = kr[8 * b + u];
+                    float p = qv.x * kk.x; dot = dot + p;
+                    p = qv.y * kk.y; dot = dot + p;
+                    p = qv.z * kk.z; dot = dot + p;
+                    p = qv.w * kk.w; dot = dot + p;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) qa[u] = qb[u];
+            }
         }
         const float sc = t < np ? dot * scale : -__builtin_inff();
         if (t < kShortMaxT) att[t] = sc;                  // all 256 slots are written: -inf beyond the context
@@ -2840,5 +2865,7 @@ __global__ __launch_bounds__(kWG) void k_op_argmax(const float* logits, size_t n
     }
     if ((threadIdx.x & 63) == 0 && best != 0ull) atomicMax(cell, best);
 }
+
+#endif  // Q3_GEMV_ONLY
 
 }  // namespace q3

@@ -621,6 +621,128 @@ def test_full_size_4b_batched_prefill_256_tokens(q3, oracle):
         assert_biteq(got3[l][1], ov[l].reshape(-1)[:3 * kvd], f"oracle value rows layer {l}")
 
 
+def test_config3_decode_past_a_2048_token_prefill_vs_oracle(q3, oracle):
+    """BASELINE config 3 past the prefill, against the ORACLE: the 4B layer dimensions (2 layers, reduced vocabulary) at
+    ctx 4096 -- a 2,048-token batched prefill (chat pattern, generation.rs:116-123) followed by 8 decode forwards at
+    positions 2,048..2,055 (the split long-context attention kernels over a prefilled cache, layers.rs:388-417).  First
+    token, every decode step's logits and the K/V rows around the hand-over are bit-identical."""
+    ck = q3.checkpoint
+    name = "qwen3-4b-dims-l2"
+    shape = ck.SHAPES[name]
+    path = os.path.join(os.environ.get("Q3_CKPT_DIR", "/tmp"), f"q3_{name}.bin")
+    ck.ensure_synthetic_checkpoint(path, shape, seed=1235)
+    S, n_prompt, n_dec = 4096, 2048, 8
+    prompt = ck.iter_prompt_tokens(shape, 1235, n_prompt)
+    om = oracle.OracleModel(path, S)
+    for p, tok in enumerate(prompt):
+        lg = om.forward(tok, p)
+    want_first = oracle.sample_argmax(lg)
+    kvd = shape.n_kv_heads * shape.head_dim
+    with q3.TransformerBuilder(path).with_ctx_length(S).build() as t:
+        assert t.prefill(prompt, 0, batched=True) == want_first
+        ok, ov = om.kv_cache()
+        for layer in range(shape.n_layers):
+            for lo, hi in ((0, 40), (1000, 1040), (n_prompt - 40, n_prompt)):
+                assert_biteq(t.read_state("key", (layer * S + lo) * kvd, (hi - lo) * kvd),
+                             ok[layer].reshape(-1)[lo * kvd:hi * kvd], f"prefill key rows {lo}..{hi} layer {layer}")
+                assert_biteq(t.read_state("value", (layer * S + lo) * kvd, (hi - lo) * kvd),
+                             ov[layer].reshape(-1)[lo * kvd:hi * kvd], f"prefill value rows {lo}..{hi} layer {layer}")
+        tok = want_first
+        for k in range(n_dec):
+            pos = n_prompt + k
+            a = np.array(t.forward(tok, pos), copy=True)
+            b = om.forward(tok, pos)
+            assert_biteq(a, b, f"decode logits at pos {pos}")
+            tok = oracle.sample_argmax(b)
+        ok, ov = om.kv_cache()
+        for layer in range(shape.n_layers):
+            lo, hi = n_prompt - 4, n_prompt + n_dec
+            assert_biteq(t.read_state("key", (layer * S + lo) * kvd, (hi - lo) * kvd),
+                         ok[layer].reshape(-1)[lo * kvd:hi * kvd], f"key rows across the hand-over, layer {layer}")
+            assert_biteq(t.read_state("value", (layer * S + lo) * kvd, (hi - lo) * kvd),
+                         ov[layer].reshape(-1)[lo * kvd:hi * kvd], f"value rows across the hand-over, layer {layer}")
+
+
+def test_full_size_4b_prefill_2048_then_decode_properties(q3):
+    """BASELINE config 3 at FULL size (Qwen3-4B shape, 36 layers, ctx 4096): 2,048-token batched prefill + 16 decode tokens.
+    Size-independent properties: the device-resident greedy loop == the forward()+argmax loop == a second run from a
+    reset cache, and the prefill's first token is reproducible."""
+    ck = q3.checkpoint
+    shape = ck.SHAPES["qwen3-4b"]
+    path = os.path.join(os.environ.get("Q3_CKPT_DIR", "/tmp"), "qwen3-4b-seed1235.q3bin")     # shared with tools/bench_chat.py
+    ck.ensure_synthetic_checkpoint(path, shape, seed=1235)
+    n_prompt, n_dec = 2048, 16
+    prompt = ck.iter_prompt_tokens(shape, 1235, n_prompt)
+    with q3.TransformerBuilder(path).with_ctx_length(4096).build() as t:
+        first = t.prefill(prompt, 0, batched=True)
+        loop = t.generate_greedy(first, n_prompt, n_dec)
+        t.reset_kv()
+        assert t.prefill(prompt, 0, batched=True) == first
+        tok, manual = first, []
+        for k in range(n_dec):
+            lg = np.array(t.forward(tok, n_prompt + k), copy=True)
+            assert np.all(np.isfinite(lg))
+            tok = int(len(lg) - 1 - np.argmax(lg[::-1]))      # last maximum (sampler.rs:57-59)
+            manual.append(tok)
+        assert manual == loop
+        t.reset_kv()
+        assert t.prefill(prompt, 0, batched=True) == first
+        assert t.generate_greedy(first, n_prompt, n_dec) == loop
+
+
+def test_deepseek_header_two_layer_dims_vs_oracle(q3, oracle, tmp_path_factory):
+    """BASELINE config 5's checkpoint header -- DeepSeek-R1-0528-Qwen3-8B: seq_len 131072 in the file, 8B layer dimensions,
+    untied classifier (README.md:37) -- on a 2-layer variant with a reduced vocabulary: the context argument clamps seq_len
+    (models/mod.rs:65-67) and the logits of the generate-mode call pattern (first forward at pos 7 over a zero KV prefix,
+    generation.rs:26-29), including positions in the split long-context plan, are bit-identical to the oracle."""
+    import dataclasses
+    ck = q3.checkpoint
+    shape = dataclasses.replace(ck.SHAPES["deepseek-r1-0528-qwen3-8b"], n_layers=2, vocab_size=16384)
+    path = str(tmp_path_factory.mktemp("ds") / "deepseek-l2.bin")
+    ck.write_synthetic_checkpoint(path, shape, seed=53)
+    with open(path, "rb") as f:
+        hdr = oracle.read_config(f.read(256))
+    assert hdr.seq_len == 131072 and not hdr.shared_classifier and hdr.dim == 4096 and hdr.hidden_dim == 12288
+    ctx = 768
+    om = oracle.OracleModel(path, ctx)
+    with q3.TransformerBuilder(path).with_ctx_length(ctx).build() as t:
+        assert t.get_config().seq_len == ctx
+        tok = 11
+        for pos in [7, 8, 9, 10, 300, 301, ctx - 1]:
+            a = np.array(t.forward(tok, pos), copy=True)
+            b = om.forward(tok, pos)
+            assert_biteq(a, b, f"pos {pos}")
+            tok = oracle.sample_argmax(b)
+        with pytest.raises(IndexError):
+            t.forward(1, ctx)
+
+
+def test_full_size_deepseek_8b_header_16_token_determinism(q3):
+    """BASELINE config 5's replica at FULL size (8.7 GB checkpoint with the 131072-position header, ctx 1024): 16 greedy
+    tokens of the device-resident loop == the forward()+argmax loop == a second run from a reset cache."""
+    ck = q3.checkpoint
+    name = "deepseek-r1-0528-qwen3-8b"
+    shape = ck.SHAPES[name]
+    path = os.path.join(os.environ.get("Q3_CKPT_DIR", "/tmp"), f"q3_{name}.bin")      # shared with bench.py other_configs
+    ck.ensure_synthetic_checkpoint(path, shape, seed=1234)
+    prompt = ck.iter_prompt_tokens(shape, 1234, 8)
+    first_tok, first_pos = prompt[-1], len(prompt) - 1
+    with q3.TransformerBuilder(path).with_ctx_length(1024).build() as t:
+        assert t.get_config().seq_len == 1024
+        loop = t.generate_greedy(first_tok, first_pos, 16)
+        t.reset_kv()
+        tok, manual = first_tok, []
+        for k in range(16):
+            lg = np.array(t.forward(tok, first_pos + k), copy=True)
+            assert np.all(np.isfinite(lg))
+            tok = int(len(lg) - 1 - np.argmax(lg[::-1]))
+            manual.append(tok)
+        assert manual == loop
+        t.reset_kv()
+        assert t.generate_greedy(first_tok, first_pos, 16) == loop
+        assert len(set(loop)) > 4
+
+
 @pytest.mark.parametrize("n_heads,n_kv,hd", [(4, 4, 32), (8, 1, 64), (6, 2, 128)])
 def test_batched_paths_other_head_layouts(q3, n_heads, n_kv, hd, tmp_path_factory):
     """kv_mul 1 (no sharing, head_dim < 64), kv_mul 8 (falls back to the per-head attention kernel; batched prefill then
