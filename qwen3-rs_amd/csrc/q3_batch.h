@@ -432,6 +432,162 @@ __global__ __launch_bounds__(kBThreads) void k_bgemm(const BGemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Dense prefill matmul (round 3): M = 64..256 positions of ONE sequence per weight pass (q3_prefill_batched), group 64.
+// At 32 columns the matrix cores idle (MFMA busy ~5 %) and k_bgemm splits K over the waves of a workgroup, exchanging the
+// f32 group terms through a 64 KiB LDS tile with two barriers per phase.  With >= 64 positions there are enough
+// (row tile, position tile) pairs to give every WAVE an output tile for the whole contraction: RT row tiles x PT position
+// tiles, RT*PT MFMAs per quantization group, and lane l (position s = l % 16, rows 4*(l/16)+i) adds its group terms
+//     acc[rt][pt][i] += ((f32)idot * ws[row][g]) * xs[pos][g]            g ascending, from -0.0
+// itself -- the order of tensor.rs:53-60, no term tile, no barrier, no K split.  Weight and activation fragments are
+// requested two groups ahead: the same 1 KiB-per-wave contiguous loads of the packed layout as k_bgemm.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPgThreads = 256;
+template <int EPI, int RT, int PT, int DEPTH = 4>
+__global__ __launch_bounds__(kPgThreads) void k_pgemm(const BGemmArgs a) {
+    static_assert(EPI != EPI_SWIGLU || (RT % 2) == 0, "SwiGLU tasks hold w1 tiles and their w3 tiles");
+    // prefetch depth in groups, the SAME for weight and activation fragments: loads retire in order, so a shallower ring for
+    // the (L2-resident) activations made every wait for them a wait for the youngest weight request as well (first cut:
+    // DA = 4, DB = 2 ran the 53 MB w1|w3 pass at 1.25 TB/s)
+    // Each wave has DEPTH - 1 groups = (DEPTH - 1) * RT KiB of weights in flight; under load an HBM round trip is ~2.5 us, so the
+    // chip needs >= 12 MB requested to stream at 5 TB/s: prefer many row tiles per wave (weights) over many position tiles.
+    constexpr int DA = DEPTH, DB = DEPTH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, s = lane & 15;
+    const int ng = a.ng;
+    const int nptiles = (a.n_streams + 15) >> 4;
+    const int npg = (nptiles + PT - 1) / PT;                     // position groups per row task
+    const int ntasks = (a.ntiles / RT) * npg;
+    const size_t tile_v4 = (size_t)ng * 64;                      // v4i per packed tile (weights or activations)
+    for (int task = blockIdx.x * (kPgThreads / 64) + wave; task < ntasks; task += gridDim.x * (kPgThreads / 64)) {
+        const int rtask = task / npg, pg = task - rtask * npg;
+        const v4i* wp[RT];
+        const v4f* wsp[RT];
+        const v4i* xp[PT];
+        const float* xsp[PT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            wp[rt] = (const v4i*)a.wq + (size_t)(rtask * RT + rt) * tile_v4 + lane;
+            wsp[rt] = (const v4f*)a.ws + (size_t)(rtask * RT + rt) * ng * 4 + q;
+        }
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int ptile = min(pg * PT + pt, nptiles - 1);   // position tiles past the block re-read the last one (not stored)
+            xp[pt] = (const v4i*)a.xq + (size_t)ptile * tile_v4 + lane;
+            xsp[pt] = a.xs + (size_t)ptile * ng * 16 + s;
+        }
+        v4i fa[DA][RT], fb[DB][PT];
+        v4f fws[DA][RT];
+        float fxs[DB][PT];
+        auto load_a = [&](int slot, int g) {
+            const int gg = min(g, ng - 1);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                // plain (cacheable) loads: the position groups of a row task run as adjacent waves of one workgroup and share the
+                // weight lines through L1 / L2 -- with non-temporal loads every position group fetched the tile from HBM again
+                // (r03 sweep: w1|w3 time followed the number of position groups, 46 / 46 / 63 us for 2 / 4 / 8 groups)
+                fa[slot][rt] = wp[rt][(size_t)gg * 64];
+                fws[slot][rt] = wsp[rt][(size_t)gg * 4];
+            }
+        };
+        auto load_b = [&](int slot, int g) {
+            const int gg = min(g, ng - 1);
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                fb[slot][pt] = xp[pt][(size_t)gg * 64];
+                fxs[slot][pt] = xsp[pt][(size_t)gg * 16];
+            }
+        };
+        v4f acc[RT][PT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) acc[rt][pt] = (v4f){-0.0f, -0.0f, -0.0f, -0.0f};     // Iterator::sum::<f32>() identity
+#pragma unroll
+        for (int d = 0; d < DA - 1; ++d) { load_a(d, d); load_b(d, d); }
+        auto fold_group = [&](int slot) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const v4f wsv = fws[slot][rt];
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    const v4i c = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[slot][rt], fb[slot][pt], (v4i){0, 0, 0, 0}, 0, 0, 0);
+                    const float xsc = fxs[slot][pt];
+                    // tensor.rs:59  ((dot as f32) * ws) * xs.  Every product passes through an opaque register: plain -O3
+                    // SLP-packs the four lanes into v_pk_mul / v_pk_add, whose operand PAIRS forced register copies of
+                    // in-flight ring slots at the loop head -- each copy a wait for a load issued that same iteration
+                    // (r03 disassembly: s_waitcnt vmcnt(4) with 32 loads in the ring)
+                    float t0 = (float)c.x * wsv.x, t1 = (float)c.y * wsv.y, t2 = (float)c.z * wsv.z, t3 = (float)c.w * wsv.w;
+                    asm("" : "+v"(t0)); asm("" : "+v"(t1)); asm("" : "+v"(t2)); asm("" : "+v"(t3));
+                    t0 = t0 * xsc; t1 = t1 * xsc; t2 = t2 * xsc; t3 = t3 * xsc;
+                    asm("" : "+v"(t0)); asm("" : "+v"(t1)); asm("" : "+v"(t2)); asm("" : "+v"(t3));
+                    v4f& ac = acc[rt][pt];
+                    float a0 = ac.x + t0, a1 = ac.y + t1, a2 = ac.z + t2, a3 = ac.w + t3;
+                    asm("" : "+v"(a0)); asm("" : "+v"(a1)); asm("" : "+v"(a2)); asm("" : "+v"(a3));
+                    ac.x = a0; ac.y = a1; ac.z = a2; ac.w = a3;
+                }
+            }
+        };
+        // main loop: whole rings of DA groups, NO branch inside (a wave-uniform `if (g < ng)` here split the body into basic
+        // blocks and hipcc closed each with s_waitcnt vmcnt(0): every load was waited for in the iteration that issued it)
+        int g0 = 0;
+        for (; g0 + DA <= ng; g0 += DA) {
+#pragma unroll
+            for (int u = 0; u < DA; ++u) {
+                load_a((u + DA - 1) % DA, g0 + u + DA - 1);      // (clamped to the row: the last ring re-reads its last group)
+                load_b((u + DB - 1) % DB, g0 + u + DB - 1);
+                fold_group(u);
+                // stage boundary pinned: without it hipcc hoists the four stages' MFMAs to the top of the body behind one
+                // s_waitcnt vmcnt(0) and issues all sixteen loads as one burst behind them -- no load is in flight across a stage
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // tail: ng % DA groups, already in the ring
+#pragma unroll
+        for (int u = 0; u < DA - 1; ++u)
+            if (g0 + u < ng) fold_group(u);
+        // ---- epilogue: lane (s, q) owns out[position pg*PT*16 + pt*16 + s][rows 4q .. 4q+3 of each row tile]
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int sb = (pg * PT + pt) * 16 + s;
+            if (pg * PT + pt >= nptiles || sb >= a.n_streams) continue;
+            if constexpr (EPI == EPI_SWIGLU) {
+                // packed tiles alternate w1 | w3 of the same 16 hidden units            layers.rs:468-475
+#pragma unroll
+                for (int k = 0; k < RT / 2; ++k) {
+                    v4f o;
+                    const v4f g1 = acc[2 * k][pt], up = acc[2 * k + 1][pt];
+                    { const float den = 1.0f + q3_expf(-g1.x); o.x = (g1.x * (1.0f / den)) * up.x; }
+                    { const float den = 1.0f + q3_expf(-g1.y); o.y = (g1.y * (1.0f / den)) * up.y; }
+                    { const float den = 1.0f + q3_expf(-g1.z); o.z = (g1.z * (1.0f / den)) * up.z; }
+                    { const float den = 1.0f + q3_expf(-g1.w); o.w = (g1.w * (1.0f / den)) * up.w; }
+                    *(v4f*)(a.out0 + (size_t)sb * a.out0_stride + (size_t)(rtask * (RT / 2) + k) * 16 + 4 * q) = o;
+                }
+            } else {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const int r0 = (rtask * RT + rt) * 16 + 4 * q;
+                    const v4f o = acc[rt][pt];
+                    if constexpr (EPI == EPI_QKV) {
+                        float* dst;
+                        if (r0 < a.rows0) dst = a.out0 + (size_t)sb * a.out0_stride + r0;
+                        else if (r0 < a.rows0 + a.rows1) dst = a.out1 + (size_t)sb * a.out1_stride + (r0 - a.rows0);
+                        else dst = a.out2 + (size_t)sb * a.out2_stride + (size_t)a.st[sb].pos * a.pos_stride + (r0 - a.rows0 - a.rows1);
+                        *(v4f*)dst = o;
+                    } else if constexpr (EPI == EPI_RESID) {
+                        v4f* dst = (v4f*)(a.out0 + (size_t)sb * a.out0_stride + r0);
+                        v4f x = *dst;
+                        x.x = x.x + o.x; x.y = x.y + o.y; x.z = x.z + o.z; x.w = x.w + o.w;      // layers.rs:249-259
+                        *dst = x;
+                    } else {
+                        *(v4f*)(a.out0 + (size_t)sb * a.out0_stride + r0) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Batched attention: one workgroup per (stream, kv head).  Wave w < kv_mul owns query head kvh*kv_mul + w; the
 // extra wave normalises + rotates the key row.  The kv head's K (then V) rows are staged in LDS ONCE for all
 // kv_mul query heads (grouped-query sharing), 32 streams x 8 kv heads = 256 workgroups = one per CU.  Every
@@ -969,6 +1125,267 @@ __global__ __launch_bounds__(kG2Threads) void k_attn_gqa2(const AttnArgs a0) {
     if (head) {
         const float o[4] = {o0, o1, 0.0f, 0.0f};
         gqa_store(a0, sbi, h, hd, lane, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Prefill attention (round 3; head_dim 128, KVM = 2 or 4 query heads per kv head): one 4-wave workgroup per (kv head, FOUR
+// consecutive positions of the block).  Wave w owns position 4*blockIdx.y + w and runs the KVM query heads of the kv head
+// as interleaved chains, so
+//   * every K / V chunk (64 timesteps) is staged in LDS once for 4 positions x KVM heads -- k_attn_gqa2 stages it once per
+//     position, and at a context of 2,048 its launches moved ~0.5 GB each through L2 (12 TB/s: the staging, not the
+//     arithmetic, set their 44 us);
+//   * a lane keeps its K row in registers for all KVM dots and walks two dot chains at a time: the 10-cycle dependent add
+//     of one chain no longer leaves the SIMD idle (one chain per wave used ~40 % of the issue slots);
+//   * the V pass walks 2*KVM chains per lane (elements lane, lane+64 of every head), the probabilities arrive as scalars
+//     (v_readlane of this lane-per-timestep register), V rows are read once per timestep for all heads.
+// Arithmetic and order per (head, position) are those of k_attn_gqa2 / k_attn / the reference (layers.rs:346-419,495-506):
+// bit-identical results.  Score rows live in a global scratch row per (position, head) (they do not fit LDS for 4 x KVM
+// rows); the key rows of the whole block are already in the cache (k_knorm_rope).
+// ------------------------------------------------------------------------------------------------
+// NP = positions (= waves) per workgroup: 4 (256 threads) or 8 (512 threads: two waves per SIMD, half the staging traffic)
+__host__ __device__ inline size_t attn_pf_smem_bytes(int kvm, int npw) {
+    return 4 * (2 * (size_t)kG2Tch * (kG2Hd + kKPad) + (size_t)npw * kvm * kG2Hd * 2 + (size_t)npw * kG2Hd) + 32 * 8;
+}
+// exact sequential sum (from -0.0) of row[0 .. np): NQ float4 per lane, blocks of 4*NQ consecutive terms, terms past np are +0.0
+template <int NQ>
+__device__ __forceinline__ float row_exact_sum_regs(const float* row, int np) {
+    const int j = threadIdx.x & 63;
+    constexpr int BL = 4 * NQ;
+    v4f r[NQ];
+    float tot = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        const int t = j * BL + 4 * k;
+        v4f v = {0.f, 0.f, 0.f, 0.f};
+        if (t < np) v = *(const v4f*)(row + t);                 // (rows are padded to whole float4 of valid memory)
+        v.x = (t + 0 < np) ? v.x : 0.0f; v.y = (t + 1 < np) ? v.y : 0.0f;
+        v.z = (t + 2 < np) ? v.z : 0.0f; v.w = (t + 3 < np) ? v.w : 0.0f;
+        r[k] = v;
+        tot += (v.x + v.y) + (v.z + v.w);
+    }
+    return spec_sum_lanes(tot, (np + BL - 1) / BL, [&](float s0) {
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) s0 = chain4(s0, r[k]);
+        return s0;
+    });
+}
+__device__ __forceinline__ float row_exact_sum(const float* row, int np) {
+    if (np <= 256) return row_exact_sum_regs<1>(row, np);
+    if (np <= 512) return row_exact_sum_regs<2>(row, np);
+    if (np <= 1024) return row_exact_sum_regs<4>(row, np);
+    if (np <= 2048) return row_exact_sum_regs<8>(row, np);
+    if (np <= 4096) return row_exact_sum_regs<16>(row, np);
+    // longer rows: 64 blocks folded out of memory every round (rare: contexts beyond 4,096 positions)
+    const int j = threadIdx.x & 63;
+    const int bl = (((np + 63) >> 6) + 3) & ~3;
+    const int t0 = j * bl;
+    float tot = 0.0f;
+    for (int t = t0; t < min(t0 + bl, np); ++t) tot += row[t];
+    return spec_sum_lanes(tot, (np + bl - 1) / bl, [&](float s0) {
+        for (int t = t0; t < min(t0 + bl, np); ++t) s0 = s0 + row[t];
+        return s0;
+    });
+}
+
+template <int KVM, int NP>
+__global__ __launch_bounds__(64 * NP) void k_attn_pf(const AttnArgs a0) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int hd = kG2Hd, kld = hd + kKPad, TCH = kG2Tch, TILE = TCH * kld, NQ4 = hd / 4;
+    constexpr int kPfPos = NP, NTHR = 64 * NP, NSL = TCH * (hd / 4) / NTHR;        // staging float4 per thread: 8 / 4
+    float* tiles = (float*)smem_raw;                               // 2 x [TCH][kld]   (V: [TCH][hd])
+    float* q_s = tiles + 2 * TILE;                                 // [kPfPos][KVM][hd] normalised + rotated queries
+    float* sq = q_s + kPfPos * KVM * hd;                           // [kPfPos][KVM][hd] scratch of the norm (raw | squares)
+    float* rawb = sq + kPfPos * KVM * hd;                          // [kPfPos][hd]
+    unsigned long long* etab = (unsigned long long*)(rawb + kPfPos * hd);
+    const int kvh = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pi0 = blockIdx.y * kPfPos;
+    const int n_pos = a0.n_pos;                                    // positions in the block (>= 1); their key rows are in the cache
+    const int pi = min(pi0 + wave, n_pos - 1);
+    const bool live = pi0 + wave < n_pos;                          // wave-uniform
+    const size_t kvd = (size_t)a0.n_kv_heads * hd;
+    const int ast = a0.att_stride;
+    const int pos = __builtin_amdgcn_readfirstlane(a0.st[pi].pos);
+    const int pos_last = __builtin_amdgcn_readfirstlane(a0.st[min(pi0 + kPfPos - 1, n_pos - 1)].pos);
+    const int np = pos + 1, np_max = pos_last + 1;                 // positions of a block are consecutive and ascending
+    const float* kbase = a0.key_cache + (size_t)kvh * hd;
+    const float* vbase = a0.value_cache + (size_t)kvh * hd;
+    if (tid < 32) etab[tid] = kExp2Tab[tid];
+
+    // ---- K chunk staging: 64 rows x 32 float4 = NSL float4 per thread
+    v4f sr[NSL];
+    auto issue = [&](const float* gbase, int t0) {
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) {
+            const int idx = tid + u * NTHR;
+            const int row = min(t0 + (idx >> 5), np_max - 1), c = idx & 31;
+            sr[u] = *(const v4f*)(gbase + (size_t)row * kvd + 4 * c);
+        }
+    };
+    auto commit = [&](float* tile, int ld) {
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) {
+            const int idx = tid + u * NTHR;
+            *(v4f*)(tile + (idx >> 5) * ld + 4 * (idx & 31)) = sr[u];
+        }
+    };
+    issue(kbase, 0);
+
+    // ---- QK-RMSNorm + RoPE of this position's KVM query heads (layers.rs:346-360), one head after the other
+    {
+        const float* cs = a0.rope + (size_t)pos * hd;
+        RopeRegs rr;
+        rope_regs_load(rr, a0.q_norm_w, cs, hd);
+        float* raw_w = rawb + wave * hd;
+#pragma unroll
+        for (int h = 0; h < KVM; ++h) {
+            const float* qsrc = a0.q + (size_t)pi * a0.sb_q + (size_t)(kvh * KVM + h) * hd;
+            raw_w[lane] = qsrc[lane];
+            raw_w[lane + 64] = qsrc[lane + 64];
+            wave_lds_sync();
+            wave_norm_rope(q_s + (wave * KVM + h) * hd, raw_w, sq + (wave * KVM + h) * hd, rr, hd, 1);
+            wave_lds_sync();
+        }
+    }
+    const float scale = 1.0f / sqrtf((float)hd);                   // (head_dim as f32).sqrt().recip()
+    float* rows = a0.att_global + ((size_t)pi * a0.n_heads + (size_t)kvh * KVM) * ast;      // score row of (position, head): (pi*n_heads + head) * ast
+
+    // ---- scores: att[h][t] = (q_h . K[t]) * scale, one timestep per lane, two heads' chains at a time      layers.rs:391-401
+    for (int c0 = 0, it = 0; c0 < np_max; c0 += TCH, ++it) {
+        float* tile = tiles + (it & 1) * TILE;
+        commit(tile, kld);
+        __syncthreads();
+        if (c0 + TCH < np_max) issue(kbase, c0 + TCH);
+        if (live && c0 < np) {
+            const int t = c0 + lane;
+            v4f kr[NQ4];
+            const v4f* k4 = (const v4f*)(tile + lane * kld);
+#pragma unroll
+            for (int i = 0; i < NQ4; ++i) kr[i] = k4[i];
+#pragma unroll
+            for (int hp = 0; hp < KVM; hp += 2) {
+                const v4f* qa4 = (const v4f*)(q_s + (wave * KVM + hp) * hd);
+                const v4f* qb4 = qa4 + NQ4;
+                float d0 = -0.0f, d1 = -0.0f;
+                constexpr int QB = 4;                              // float4 of q per head and batch (the next batch is in flight)
+                v4f xa[QB], xb[QB], ya[QB], yb[QB];
+#pragma unroll
+                for (int u = 0; u < QB; ++u) { xa[u] = qa4[u]; xb[u] = qb4[u]; }
+#pragma unroll
+                for (int b = 0; b < NQ4 / QB; ++b) {
+                    if (b + 1 < NQ4 / QB) {
+#pragma unroll
+                        for (int u = 0; u < QB; ++u) { ya[u] = qa4[QB * (b + 1) + u]; yb[u] = qb4[QB * (b + 1) + u]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < QB; ++u) {
+                        const v4f kk = kr[QB * b + u];
+                        const v4f p0 = xa[u] * kk, p1 = xb[u] * kk;        // products are independent of the chains
+                        d0 = d0 + p0.x; d1 = d1 + p1.x;
+                        d0 = d0 + p0.y; d1 = d1 + p1.y;
+                        d0 = d0 + p0.z; d1 = d1 + p1.z;
+                        d0 = d0 + p0.w; d1 = d1 + p1.w;
+                    }
+#pragma unroll
+                    for (int u = 0; u < QB; ++u) { xa[u] = ya[u]; xb[u] = yb[u]; }
+                }
+                if (t < np) {
+                    rows[(size_t)hp * ast + t] = d0 * scale;
+                    rows[(size_t)(hp + 1) * ast + t] = d1 * scale;
+                }
+            }
+        }
+    }
+    __syncthreads();                                               // every wave is done with the K tiles
+    issue(vbase, 0);                                               // V chunk 0 travels under the softmax
+
+    // ---- softmax per (position, head) row (layers.rs:495-506): max, exp in place, exact sequential sum; p = e * inv is
+    // formed in the V pass (same two roundings as normalising the row first)
+    float inv[KVM];
+#pragma unroll
+    for (int h = 0; h < KVM; ++h) inv[h] = 0.0f;
+    if (live) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's score stores have landed (it reads them back)
+#pragma unroll
+        for (int h = 0; h < KVM; ++h) {
+            float* row = rows + (size_t)h * ast;
+            float m = -__builtin_inff();
+            for (int t = lane; t < np; t += 64) m = fmaxf(m, row[t]);
+            m = group_max_f32(m, 64);
+            for (int t0 = 0; t0 < np; t0 += 256) {                  // four exps per lane at a time (their f64 chains interleave)
+                float ev[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + 64 * u + lane;
+                    const float x = row[min(t, np - 1)];
+                    ev[u] = q3_expf_t(x - m, etab);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + 64 * u + lane;
+                    if (t < np) row[t] = ev[u];
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const float sum = row_exact_sum(row, np);
+            inv[h] = 1.0f / sum;
+        }
+    }
+
+    // ---- xb = sum_t att[t] * V[t]  (fill(0.0) then += in t order): 2 * KVM chains per lane              layers.rs:406-417
+    float o0[KVM], o1[KVM];
+#pragma unroll
+    for (int h = 0; h < KVM; ++h) { o0[h] = 0.0f; o1[h] = 0.0f; }
+    for (int c0 = 0, it = 0; c0 < np_max; c0 += TCH, ++it) {
+        float* tile = tiles + (it & 1) * TILE;
+        commit(tile, hd);
+        __syncthreads();
+        if (c0 + TCH < np_max) issue(vbase, c0 + TCH);
+        if (live && c0 < np) {
+            float pe[KVM];
+#pragma unroll
+            for (int h = 0; h < KVM; ++h) {
+                const int t = c0 + lane;
+                const float e = rows[(size_t)h * ast + min(t, np - 1)];
+                pe[h] = (t < np) ? e * inv[h] : 0.0f;              // layers.rs:503-505; +0.0 past the context
+            }
+            const int cnt = min(TCH, np - c0);
+            const float* v0 = tile + lane;
+            auto step = [&](int tt) {
+                const float va = v0[tt * hd], vb = v0[tt * hd + 64];
+#pragma unroll
+                for (int h = 0; h < KVM; ++h) {
+                    const float p = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pe[h]), tt));
+                    const float x0 = p * va, x1 = p * vb;
+                    o0[h] = o0[h] + x0;
+                    o1[h] = o1[h] + x1;
+                }
+            };
+            if (cnt == TCH) {
+#pragma unroll 16
+                for (int tt = 0; tt < TCH; ++tt) step(tt);
+            } else {
+                // the context's last chunk: timesteps past it would add p = +0.0 times a finite V row (o + 0.0 == o, o is never
+                // -0.0), but the V tile rows past np_max were clamped re-reads -- still finite; walk only the live ones
+#pragma unroll 1
+                for (int tb = 0; tb < TCH; tb += 8) {
+                    if (tb < cnt) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) if (tb + u < cnt) step(tb + u);
+                    }
+                }
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int h = 0; h < KVM; ++h) {
+            const float o[4] = {o0[h], o1[h], 0.0f, 0.0f};
+            gqa_store(a0, (size_t)pi, kvh * KVM + h, hd, lane, o);
+        }
     }
 }
 
