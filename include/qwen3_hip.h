@@ -133,7 +133,7 @@ int q3_reset_kv(q3_engine* e);
 int q3_read_state(q3_engine* e, int kind, size_t offset, size_t count, float* out);
 
 /* Per-kernel timing of one forward(token,pos), launched eagerly with HIP events around every kernel
- * on the engine's stream.  Kernel families are listed by q3_profile_names(); ms[i] / launches[i] are
+ * on the engine's stream.  Kernel family i is named by q3_profile_name(i); ms[i] / launches[i] are
  * accumulated over `reps` forwards.  Returns the number of families (<= cap). */
 int q3_profile(q3_engine* e, size_t token, size_t pos, int reps, float* ms, int32_t* launches, int cap);
 const char* q3_profile_name(int family);
@@ -142,6 +142,9 @@ const char* q3_profile_name(int family);
 int q3_parse_header(const uint8_t* data, size_t len, q3_config* out);
 
 uint32_t q3_abi_version(void);
+/* First 16 hex digits of the SHA-256 over the library's sources (csrc/ + this header, in sorted file-name order), baked in by
+ * the Makefile: lets a test harness detect a prebuilt libqwen3_hip.so that does not match the checked-out sources. */
+const char* q3_build_id(void);
 
 /* ------------------------------------------------------------------------------------------------
  * 2b. Batched decode: up to 32 independent streams (each its own KV cache, token and position) advance

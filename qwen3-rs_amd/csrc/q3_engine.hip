@@ -889,6 +889,10 @@ extern "C" {
 
 const char* q3_last_error(void) { return g_err; }
 uint32_t q3_abi_version(void) { return Q3_ABI_VERSION; }
+#ifndef Q3_BUILD_ID
+#define Q3_BUILD_ID "unknown"
+#endif
+const char* q3_build_id(void) { return Q3_BUILD_ID; }
 
 int q3_parse_header(const uint8_t* data, size_t len, q3_config* out) {
     g_err[0] = 0;
@@ -1184,14 +1188,19 @@ int q3_host_generate(q3_engine* e, size_t first_token, size_t first_pos, size_t 
         const float* lg = q3_forward(e, token, first_pos + k);
         if (!lg) return Q3_ERR_HIP;
         memcpy(copy.data(), lg, 4 * V);                                   // generation.rs:160  logits.to_vec()
-        size_t best = 0;
+        // Iterator::max_by(total_cmp): the LAST maximum under the IEEE total order (sampler.rs:57-59).  Two passes the compiler
+        // vectorises: the maximum key (a plain max reduction over int32 keys), then a scan from the END for its first match.
+        const int32_t* bits = (const int32_t*)copy.data();
         int32_t best_key = INT32_MIN;
-        bool have = false;
-        for (size_t i = 0; i < V; ++i) {                                  // Iterator::max_by(total_cmp): last maximum
-            int32_t b;
-            memcpy(&b, &copy[i], 4);
-            const int32_t key = b < 0 ? (b ^ 0x7fffffff) : b;
-            if (!have || key >= best_key) { best_key = key; best = i; have = true; }
+        for (size_t i = 0; i < V; ++i) {
+            const int32_t b = bits[i];
+            const int32_t key = b ^ ((b >> 31) & 0x7fffffff);            // total_cmp key: negative floats order reversed
+            best_key = key > best_key ? key : best_key;
+        }
+        size_t best = 0;
+        for (size_t i = V; i-- > 0;) {
+            const int32_t b = bits[i];
+            if ((b ^ ((b >> 31) & 0x7fffffff)) == best_key) { best = i; break; }
         }
         out_tokens[k] = (int32_t)best;
         token = best;
@@ -1431,7 +1440,8 @@ int q3_op_attention(float* xb, float* q, float* key_cache_layer, const float* va
     return Q3_OK;
 }
 
-/* developer micro-benchmark (not part of the drop-in surface): average device time of the stand-alone
+#ifdef Q3_DEV
+/* developer micro-benchmark (not part of the drop-in surface; exported by the -DQ3_DEV build only): average device time of the stand-alone
  * W8A8 GEMV (PRO_PREQ/EPI_STORE) over `reps` launches on random weights resident in HBM.  ru/ju/wg_per_cu
  * <= 0 pick the planner's choice.  Distinct weight copies are cycled so nothing stays cache-resident. */
 int q3_dev_bench_gemv(size_t n, size_t d, size_t group_size, int wg_per_cu, int ru, int ju, int reps, int device,
@@ -1495,6 +1505,8 @@ int q3_dev_bench_gemv(size_t n, size_t d, size_t group_size, int wg_per_cu, int 
     if (used) { used[0] = gs.RU; used[1] = gs.JU; used[2] = (int)gs.grid; }
     return op_end();
 }
+
+#endif  // Q3_DEV
 
 int q3_op_sample(const float* logits, size_t n, float temperature, float topp, uint64_t* rng_state, int32_t* index, int device) {
     int rc = op_begin(device);

@@ -2091,10 +2091,17 @@ constexpr int kPLds = 8192;    // probability rows up to this length live in LDS
 __host__ __device__ inline size_t attn_scores_smem_bytes(int hd) {
     return 4 * ((size_t)hd * 6 + 64 + (size_t)attn_tch(hd) * (hd + kKPad));
 }
+constexpr int kEscFloats = 64 * (64 + kSpecPad);     // 4352
+__host__ __device__ inline size_t attn_out_vtile_floats(int w) {
+    const size_t v = 2 * (size_t)(kVChunk + kVPad) * w;
+    return v > (size_t)kEscFloats ? v : (size_t)kEscFloats;
+}
 __host__ __device__ inline bool attn_out_p_in_lds(int seq_len) { return ((seq_len + 255) & ~255) <= kPLds; }
 __host__ __device__ inline size_t attn_out_smem_bytes(int hd, int seq_len, int w) {
     const int pl = ((seq_len + 255) & ~255) <= kPLds ? ((seq_len + 255) & ~255) : 0;
-    return 4 * (2 * (size_t)(kVChunk + kVPad) * w + 2 * kVChunk + 64 + (size_t)16 * w + (size_t)pl) + 16 * 32 * 8;   // V / p chunk tiles double buffered; [kAoWaves][w] partials; one exp2 table per wave
+    // V / p chunk tiles double buffered; [kAoWaves][w] partials; one exp2 table per wave.  The V tiles double as the padded
+    // copy of the exps for the exact sum (k_attn_out `esc`: up to 64 blocks x (64 + kSpecPad) floats), so they hold at least that
+    return 4 * (attn_out_vtile_floats(w) + 2 * kVChunk + 64 + (size_t)16 * w + (size_t)pl) + 16 * 32 * 8;
 }
 
 __global__ __launch_bounds__(kWG) void k_attn_scores(const AttnArgs a) {
@@ -2379,7 +2386,7 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
     const int hd = a.hd;
     const int w = W_T ? W_T : a.slice_w;                 // slice width (power of two >= 8, or hd)
     float* vbuf0 = (float*)smem_raw;                     // 2 x [kVChunk][w]  (reference order: [w][kVChunk + kVPad])
-    float* pbuf0 = vbuf0 + 2 * (kVChunk + kVPad) * w;    // 2 x [kVChunk]
+    float* pbuf0 = vbuf0 + attn_out_vtile_floats(w);     // 2 x [kVChunk]  (behind the V tiles / the padded exps, whichever is larger)
     float* red = pbuf0 + 2 * kVChunk;                    // [64]
     float* opart = red + 64;                             // [kAoWaves][w]
     float* p_lds = opart + kAoWaves * w;                   // [npad] when the row fits (see attn_out_smem_bytes)
@@ -2468,7 +2475,7 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
     while (64 * bl < np) bl <<= 1;                       // 4 .. 64 for np <= 4096
     const bool padded = a.strict && bl <= 64;
     const int blsh = __builtin_ctz(bl);
-    float* esc = vbuf0;                                  // (np/bl) x (bl + 4) floats <= 4352 <= one V tile of any slice width
+    float* esc = vbuf0;                                  // (np/bl) x (bl + 4) floats <= kEscFloats: the V-tile region reserves that much
     float m = -__builtin_inff();
     const bool one_trip = np <= kAoSv * kAoThreads;
 #pragma unroll

@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "q3_create", "q3_get_config", "q3_forward", "q3_destroy", "q3_last_error", "q3_forward_argmax",
     "q3_generate_greedy", "q3_host_generate", "q3_prefill", "q3_reset_kv", "q3_read_state", "q3_batch_init", "q3_forward_batch",
     "q3_generate_greedy_batch", "q3_batch_reset_kv", "q3_batch_read_state", "q3_prefill_batched", "q3_batch_sampler_set", "q3_sampler_set", "q3_sampler_get_rng", "q3_forward_sample", "q3_generate_sampled", "q3_profile", "q3_profile_name", "q3_parse_header",
-    "q3_abi_version", "q3_op_quantize", "q3_op_dequantize", "q3_op_matmul", "q3_op_rmsnorm", "q3_op_softmax",
+    "q3_abi_version", "q3_build_id", "q3_op_quantize", "q3_op_dequantize", "q3_op_matmul", "q3_op_rmsnorm", "q3_op_softmax",
     "q3_op_swiglu", "q3_op_expf", "q3_op_attention", "q3_op_argmax", "q3_op_sample",
 ]
 
@@ -65,6 +65,18 @@ def lib_path() -> str:
 _lib: Optional[C.CDLL] = None
 
 
+def source_build_id() -> str:
+    """The id `make` bakes into the library: sha256 over csrc/* and include/qwen3_hip.h in sorted order (first 16 hex digits)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_DIST_DIR, "csrc", "*"))) + [os.path.join(os.path.dirname(_DIST_DIR), "include", "qwen3_hip.h")]
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def load_library() -> C.CDLL:
     """Load libqwen3_hip.so.  Fails loudly: the HIP library is the product, there is nothing to fall back to."""
     global _lib
@@ -77,6 +89,7 @@ def load_library() -> C.CDLL:
     fp, i8p, u8p, sz = C.POINTER(C.c_float), C.POINTER(C.c_int8), C.POINTER(C.c_uint8), C.c_size_t
     L.q3_last_error.restype = C.c_char_p
     L.q3_abi_version.restype = C.c_uint32
+    L.q3_build_id.restype = C.c_char_p
     L.q3_create.argtypes = [C.c_char_p, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
     L.q3_get_config.argtypes = [C.c_void_p, C.POINTER(_Config)]
     L.q3_forward.argtypes = [C.c_void_p, sz, sz]
@@ -305,7 +318,7 @@ class TransformerBuilder:
         self.checkpoint_path = checkpoint_path
         self.ctx_length: Optional[int] = None
         self.device = int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("Q3_DEVICE_FROM_RANK") else 0
-        # Q3_EAGER=1: launch kernels eagerly instead of replaying hipGraphs (profiling runs: rocprofv3's kernel trace
+        # Q3_EAGER_LAUNCH=1: launch kernels eagerly instead of replaying hipGraphs (profiling runs: rocprofv3's kernel trace
         # of this ROCm build crashes on long back-to-back graph replays)
         self.flags = FLAG_NO_GRAPH if os.environ.get("Q3_EAGER_LAUNCH") else 0
 

@@ -38,12 +38,20 @@ def q3():
     import shutil
     import subprocess
     lib = qwen3_rs_amd.lib_path()
-    # the build container (where sources are edited) always runs make: a no-op when the library is newer than every
-    # source/header the Makefile lists.  Elsewhere (the GPU box gets the prebuilt .so with the snapshot, whose file
-    # times are not to be trusted) only a missing library is built.
-    dev_box = os.path.isdir("/root/reference")
-    if "Q3_HIP_LIB" not in os.environ and shutil.which("make") and (dev_box or not os.path.exists(lib)):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "qwen3-rs_amd")])
+    # A prebuilt library ships with every gpurun snapshot (untracked *.so travel).  It is used only if it was built from
+    # the checked-out sources: q3_build_id() (a hash of csrc/* + the header baked in by make) must equal the hash of the
+    # sources here; otherwise it is rebuilt, and if that is impossible the session fails instead of testing a stale binary.
+    if "Q3_HIP_LIB" not in os.environ:
+        want = qwen3_rs_amd.source_build_id()
+
+        # (the id is read in a child process: a stale library must not stay mapped in this one)
+        code = ("import ctypes,sys\ntry:\n L=ctypes.CDLL(sys.argv[1]); L.q3_build_id.restype=ctypes.c_char_p; print(L.q3_build_id().decode())\n"
+                "except Exception as e: print('unreadable')")
+        have = subprocess.run([sys.executable, "-c", code, lib], capture_output=True, text=True).stdout.strip() if os.path.exists(lib) else None
+        if have != want:
+            if not shutil.which("make"):
+                raise RuntimeError(f"{lib} was built from other sources (build id {have}, sources {want}) and there is no make to rebuild it")
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "qwen3-rs_amd")])
     qwen3_rs_amd.load_library()
     return qwen3_rs_amd
 

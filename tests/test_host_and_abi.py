@@ -15,7 +15,6 @@ from conftest import ROOT, golden_path
 def test_library_exports_every_declared_symbol(q3):
     hdr = open(os.path.join(ROOT, "include", "qwen3_hip.h")).read()
     declared = set(re.findall(r"\b(q3_[a-z0-9_]+)\s*\(", hdr))
-    declared.discard("q3_profile_names")  # only mentioned in a comment
     assert declared, "no declarations parsed"
     assert declared == set(q3.EXPORTED_SYMBOLS), declared ^ set(q3.EXPORTED_SYMBOLS)
     lib = q3.load_library()
@@ -24,7 +23,12 @@ def test_library_exports_every_declared_symbol(q3):
     out = subprocess.check_output(["nm", "-D", "--defined-only", q3.lib_path()], text=True)
     exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
     assert declared <= exported
+    # developer entry points are compiled in only with -DQ3_DEV (libqwen3_hip_dev.so), never exported by the product library
+    assert not {e for e in exported if e.startswith("q3_dev_")}, "q3_dev_* symbols in the product library"
     assert lib.q3_abi_version() == 1
+    # the library was built from the checked-out sources (q3_build_id = hash of csrc/* + the header, baked in by make)
+    if "Q3_HIP_LIB" not in os.environ:
+        assert lib.q3_build_id().decode() == q3.source_build_id()
 
 
 def test_no_cpu_fallback_without_gpu(q3):
