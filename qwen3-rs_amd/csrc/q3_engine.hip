@@ -201,6 +201,9 @@ struct q3_engine {
     std::vector<Launch> plan, plan_long;
     hipGraph_t graph = nullptr, graph_long = nullptr;
     hipGraphExec_t graph_exec = nullptr, graph_long_exec = nullptr;
+    // q3_forward as ONE graph launch: state upload (pinned h_state) -> the token's kernels -> logits download (pinned h_logits)
+    hipGraph_t graph_fwd = nullptr, graph_fwd_long = nullptr;
+    hipGraphExec_t graph_fwd_exec = nullptr, graph_fwd_long_exec = nullptr;
     float* d_att_priv = nullptr;
     int cmax_stride = 0;
     int att_stride = 0;
@@ -389,6 +392,10 @@ void q3_engine::release() {
     if (graph) (void)hipGraphDestroy(graph);
     if (graph_long_exec) (void)hipGraphExecDestroy(graph_long_exec);
     if (graph_long) (void)hipGraphDestroy(graph_long);
+    if (graph_fwd_exec) (void)hipGraphExecDestroy(graph_fwd_exec);
+    if (graph_fwd) (void)hipGraphDestroy(graph_fwd);
+    if (graph_fwd_long_exec) (void)hipGraphExecDestroy(graph_fwd_long_exec);
+    if (graph_fwd_long) (void)hipGraphDestroy(graph_fwd_long);
     void* dptrs[] = {d_next_cell, d_xbq, d_xbs, d_sampler, d_probs, d_sp, d_keys, d_prompt, d_att_priv, d_argmax_slots, d_stamps, d_blob, d_x, d_q, d_kraw, d_xb, d_hb, d_logits, d_tap, d_key, d_value, d_rope, d_att, d_state, d_out_tokens};
     for (void* p : dptrs)
         if (p) (void)hipFree(p);
@@ -846,6 +853,17 @@ int q3_engine::capture() {
     for (const Launch& L : plan_long) launch_one(L, this);
     HIP_TRY(hipStreamEndCapture(stream, &graph_long));
     HIP_TRY(hipGraphInstantiate(&graph_long_exec, graph_long, nullptr, nullptr, 0));
+    if (env_int("Q3_FWD_GRAPH", 1)) {
+        const size_t lbytes = 4 * (size_t)cfg.vocab_size;
+        for (int lng = 0; lng < 2; ++lng) {
+            HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            HIP_TRY(hipMemcpyAsync(d_state, h_state, sizeof(State), hipMemcpyHostToDevice, stream));
+            for (const Launch& L : (lng ? plan_long : plan)) launch_one(L, this);
+            HIP_TRY(hipMemcpyAsync(h_logits, d_logits, lbytes, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamEndCapture(stream, lng ? &graph_fwd_long : &graph_fwd));
+            HIP_TRY(hipGraphInstantiate(lng ? &graph_fwd_long_exec : &graph_fwd_exec, lng ? graph_fwd_long : graph_fwd, nullptr, nullptr, 0));
+        }
+    }
     return Q3_OK;
 }
 
@@ -946,6 +964,25 @@ const float* q3_forward(q3_engine* e, size_t token, size_t pos) {
     struct timespec t0, t1, t2, t3, t4;
     if (dbg) clock_gettime(CLOCK_MONOTONIC, &t0);
     if (hipSetDevice(e->device) != hipSuccess) { fail(Q3_ERR_HIP, "hipSetDevice failed"); return nullptr; }
+    if (e->graph_fwd_exec && !e->sampling) {
+        // one graph launch: state upload, kernels, logits download (the three separate enqueues cost ~25 us of host time)
+        if (token >= (size_t)e->cfg.vocab_size || pos >= (size_t)e->cfg.seq_len) {
+            fail(Q3_ERR_ARG, "index out of range: token %zu (vocab_size %d), pos %zu (seq_len %d)", token, e->cfg.vocab_size, pos, e->cfg.seq_len);
+            return nullptr;
+        }
+        e->h_state->token = (int)token;
+        e->h_state->pos = (int)pos;
+        e->h_state->step = 0;
+        e->h_state->prompt_len = 0;
+        e->h_state->argmax = 0ull;
+        hipError_t ge = hipGraphLaunch((int64_t)pos >= (int64_t)e->split_pos ? e->graph_fwd_long_exec : e->graph_fwd_exec, e->stream);
+        if (ge == hipSuccess) ge = hipStreamSynchronize(e->stream);
+        if (ge != hipSuccess) {
+            fail(Q3_ERR_HIP, "forward failed: %s", hipGetErrorString(ge));
+            return nullptr;
+        }
+        return e->h_logits;
+    }
     if (e->set_state(token, pos) != Q3_OK) return nullptr;
     if (dbg) clock_gettime(CLOCK_MONOTONIC, &t1);
     if (e->enqueue_forward(false, pos, false) != Q3_OK) return nullptr;
