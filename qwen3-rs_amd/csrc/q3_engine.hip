@@ -882,6 +882,7 @@ int q3_engine::enqueue_forward(bool eager, size_t pos, bool draw) {
 // Sampler::sample on the logits of the forward just enqueued (after k_next has advanced the state)
 int q3_engine::enqueue_sample() {
     if (!sampling) return Q3_OK;
+    if (sargs.pre_exp) hipLaunchKernelGGL(k_sample_exp, dim3((unsigned)n_cu, 1), dim3(256), 0, stream, sargs);
     hipLaunchKernelGGL(k_sample, dim3(1), dim3(kSampThreads), 4 * kSegFloats, stream, sargs);
     HIP_TRY(hipGetLastError());
     return Q3_OK;
@@ -1117,6 +1118,7 @@ int q3_sampler_set(q3_engine* e, float temperature, float topp, uint64_t rng_see
     a.st = e->d_state;
     a.out_tokens = e->d_out_tokens;
     a.out_cap = e->out_cap;
+    a.pre_exp = env_int("Q3_SAMPLER_PRE_EXP", 1);
     e->sargs = a;
     e->sampling = temperature != 0.0f;                       // sampler.rs:119-120: temperature 0 is the argmax path
     return Q3_OK;

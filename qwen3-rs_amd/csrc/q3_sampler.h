@@ -42,6 +42,9 @@ struct SampleArgs {
     int out_cap;
     // batched decode: workgroup b of the launch samples stream b; element strides between streams (0 for one stream)
     long long sb_logits, sb_scratch, sb_keys;
+    // the engine's draws: e = exp(logit / T - max) was already written to probs[] by k_sample_exp (all CUs) -- the pass is
+    // ~152k IEEE divisions + f64-pipe exps, ~0.2 ms when a single workgroup walks it
+    int pre_exp;
 };
 
 __device__ __forceinline__ float key_to_float(unsigned k) {
@@ -301,16 +304,19 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a_in) 
     if (discard) return;
 
     const int n = a.n, blen = a.blen;
-    // ---- logits / temperature, max                                              sampler.rs:124-126, layers.rs:496
-    float m = -__builtin_inff();
-    for (int i = tid; i < n; i += kSampThreads) m = fmaxf(m, a.logits[i] / temperature);
-    m = group_max_f32(m, 64);
-    if (lane == 0) fred[wave] = m;
-    __syncthreads();
-    m = fred[0];
-    for (int w = 1; w < kSampThreads / 64; ++w) m = fmaxf(m, fred[w]);
-    // ---- e = exp(x - max), exact sum in index order, p = e * (1/sum)             layers.rs:497-505
-    for (int i = tid; i < n; i += kSampThreads) a.probs[i] = q3_expf(a.logits[i] / temperature - m);
+    if (!a.pre_exp) {
+        // ---- logits / temperature, max                                              sampler.rs:124-126, layers.rs:496
+        float m = -__builtin_inff();
+        for (int i = tid; i < n; i += kSampThreads) m = fmaxf(m, a.logits[i] / temperature);
+        m = group_max_f32(m, 64);
+        if (lane == 0) fred[wave] = m;
+        __syncthreads();
+        m = fred[0];
+        for (int w = 1; w < kSampThreads / 64; ++w) m = fmaxf(m, fred[w]);
+        // ---- e = exp(x - max)                                                        layers.rs:497-501
+        for (int i = tid; i < n; i += kSampThreads) a.probs[i] = q3_expf(a.logits[i] / temperature - m);
+    }
+    // ---- exact sum in index order, p = e * (1/sum)                                  layers.rs:502-505
     __syncthreads();
     const float esum = wg_walk_segments(a.probs, n, -0.0f, seg, xch, &carry_lds, &ss->rounds[0],   // Iterator::sum from -0.0
                                         [](int, float, float) { return false; });
@@ -444,6 +450,22 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a_in) 
         const int s = st->step - 1;
         if (s >= 0 && s < a.out_cap) a.out_tokens[s] = result;
     }
+}
+
+// The first two passes of Sampler::sample spread over the chip (grid: workgroups x streams): x = logit / T (sampler.rs:124-126),
+// e = exp(x - max) (layers.rs:496-501).  The maximum of the scaled logits is RN(l_max / T): division by T > 0 and its rounding
+// are monotone, so it is the scaled value of the largest logit -- which the classifier launch already left in State::argmax
+// (total-order key of the best logit).  Element-wise and order-free: bit-identical to the in-kernel passes of k_sample.
+__global__ __launch_bounds__(256) void k_sample_exp(const SampleArgs a_in) {
+    const size_t sb = blockIdx.y;
+    const State* st = a_in.st + sb;
+    if (st->step < st->prompt_len) return;                     // a discarded prompt-position draw
+    const SamplerState* ss = a_in.ss + sb;
+    const float temperature = ss->temperature;
+    const float* logits = a_in.logits + sb * a_in.sb_logits;
+    float* probs = a_in.probs + sb * a_in.sb_scratch;
+    const float m = key_to_float((unsigned)(st->argmax >> 32)) / temperature;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a_in.n; i += gridDim.x * 256) probs[i] = q3_expf(logits[i] / temperature - m);
 }
 
 // advance the xorshift64* stream by `count` coins (batched prefill: one discarded sample per prompt position)
