@@ -303,7 +303,7 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a_in) 
     if (tid == 0) ss->rng = rs;
     if (discard) return;
 
-    const int n = a.n, blen = a.blen;
+    const int n = a.n;
     if (!a.pre_exp) {
         // ---- logits / temperature, max                                              sampler.rs:124-126, layers.rs:496
         float m = -__builtin_inff();
@@ -339,56 +339,78 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a_in) 
     } else {
         // ---- sample_topp                                                          sampler.rs:74-112
         const float cutoff = (1.0f - topp) / (float)((n - 1) > 1 ? (n - 1) : 1);
-        const int i0 = tid * blen, i1 = min(i0 + blen, n);
         // Only the head of the sorted candidate list is ever walked (until the cumulative probability exceeds topp), and
-        // "all candidates whose probability key is >= T" is exactly a prefix of that list for any T.  A 2048-bin
-        // histogram of the keys (mass per bin, any order: heuristic only) picks a T that should cover topp; if the exact
-        // walk over that prefix does not cross topp after all, the second attempt sorts every candidate.
+        // "all candidates whose probability key is >= T" is exactly a prefix of that list for any T.  A histogram of the keys
+        // (mass per 2^-3-binade bin, any order: heuristic only) picks a T that should cover topp; if the exact walk over that
+        // prefix does not cross topp after all, the second attempt sorts every candidate.
+        // Round 3: every pass over the vocabulary is COALESCED (thread i takes i, i + 1024, ...; the index-ordered compaction
+        // gives each wave a contiguous range and ranks with ballots) -- the thread-contiguous blocks of round 2 touched 64
+        // cache lines per load instruction, ~0.2 ms per pass on one CU.  The histogram only covers the 64 bins below the
+        // largest probability (p_max = 1 * inv: the exp of the maximum is 1): the nucleus of a peaked distribution lives there,
+        // the mass of the (many) tokens below the window is irrelevant, and their LDS atomics -- tens of thousands on a
+        // handful of hot bins -- were the most expensive part of the draw.  A wave whose 64 values share a bin adds once.
         for (int i = tid; i < 2048; i += kSampThreads) hmass[i] = 0.0f;
         __syncthreads();
-        for (int i = i0; i < i1; ++i) {
-            const float p = a.probs[i];
-            if (p >= cutoff) atomicAdd(&hmass[total_order_key(p) >> 21], p);
+        const unsigned bmax = total_order_key(inv) >> 21;
+        const unsigned bfloor = bmax > 64u ? bmax - 64u : 0u;
+        for (int i0 = 0; i0 < n; i0 += kSampThreads) {
+            const int i = i0 + tid;
+            const float p = i < n ? a.probs[i] : 0.0f;
+            const unsigned bin = total_order_key(p) >> 21;
+            const bool in = i < n && p >= cutoff && bin >= bfloor;
+            const unsigned tag = in ? bin : 0xffffffffu;
+            const unsigned first = (unsigned)__builtin_amdgcn_readfirstlane((int)tag);
+            if (__all(tag == first)) {                         // wave-uniform bin (or nothing to add)
+                if (first != 0xffffffffu) {
+                    const float sw = group_sum_f32(p, 64);
+                    if (lane == 0) atomicAdd(&hmass[first], sw);
+                }
+            } else if (in) atomicAdd(&hmass[bin], p);
         }
         __syncthreads();
         if (tid == 0) {
             float acc = 0.0f;
             int b = 2047;
-            for (; b > 0; --b) {
+            bool found = false;
+            for (; b > (int)bfloor; --b) {
                 acc += hmass[b];
-                if (acc > topp * 1.001f + 1e-6f) break;
+                if (acc > topp * 1.001f + 1e-6f) { found = true; break; }
             }
-            ired[16] = b > 0 ? b - 1 : 0;                  // one bin of margin
+            ired[16] = (found && b > 0) ? b - 1 : 0;       // one bin of margin; nucleus below the window: every candidate
         }
         __syncthreads();
         const unsigned tkey0 = (unsigned)ired[16] << 21;
         int n0 = 0, hit = 0;
         const unsigned long long* sorted = a.keys;
+        constexpr int NW = kSampThreads / 64;
+        const int per_wave = ((n + NW * 64 - 1) / (NW * 64)) * 64;
+        const int w0 = min(wave * per_wave, n), w1 = min(w0 + per_wave, n);
         for (int attempt = 0; attempt < 2; ++attempt) {
             const unsigned tkey = attempt == 0 ? tkey0 : 0u;
             __syncthreads();
-            // candidates in index order: lane j owns indices [j*blen, (j+1)*blen)
+            // candidates in index order: wave w owns the contiguous index range [w0, w1), 64 consecutive indices per load
             int cnt = 0;
-            for (int i = i0; i < i1; ++i) {
-                const float p = a.probs[i];
-                cnt += (p >= cutoff && total_order_key(p) >= tkey) ? 1 : 0;
+            for (int base = w0; base < w1; base += 64) {
+                const int i = base + lane;
+                const float p = i < w1 ? a.probs[i] : 0.0f;
+                const bool c = i < w1 && p >= cutoff && total_order_key(p) >= tkey;
+                cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(c));
             }
-            int inc = cnt;                                 // exclusive scan of the counts over the workgroup
-            for (int d = 1; d < 64; d <<= 1) {
-                const int o = __shfl_up(inc, d);
-                if (lane >= d) inc += o;
-            }
-            if (lane == 63) ired[wave] = inc;
+            if (lane == 0) ired[wave] = cnt;
             __syncthreads();
             int off = 0;
             for (int w = 0; w < wave; ++w) off += ired[w];
             n0 = 0;
-            for (int w = 0; w < kSampThreads / 64; ++w) n0 += ired[w];
-            int pos = off + inc - cnt;
-            for (int i = i0; i < i1; ++i) {
-                const float p = a.probs[i];
-                if (p >= cutoff && total_order_key(p) >= tkey)
-                    a.keys[pos++] = ((unsigned long long)total_order_key(p) << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+            for (int w = 0; w < NW; ++w) n0 += ired[w];
+            int run = off;
+            for (int base = w0; base < w1; base += 64) {
+                const int i = base + lane;
+                const float p = i < w1 ? a.probs[i] : 0.0f;
+                const bool c = i < w1 && p >= cutoff && total_order_key(p) >= tkey;
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(c);
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                if (c) a.keys[run + rank] = ((unsigned long long)total_order_key(p) << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+                run += __builtin_popcountll(mask);
             }
             int n2 = 1;
             while (n2 < n0) n2 <<= 1;
