@@ -1390,19 +1390,262 @@ __global__ __launch_bounds__(64 * NP) void k_attn_pf(const AttnArgs a0) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_attn_pf2: k_attn_pf with the wave-uniform operands in SCALAR registers.  Same work split (one workgroup per kv head x NP
+// consecutive positions, wave = position, K / V chunks staged in LDS once for NP x KVM query rows), same arithmetic and order,
+// but
+//   * q is normalised + rotated by k_knorm_rope (one launch for the block's K and q heads) and stored pair-interleaved; the
+//     score loop reads it with s_load (constant address space) and forms TWO heads' products with one v_pk_mul_f32
+//     (K element broadcast) and extends TWO chains with one v_pk_add_f32: 2 VALU per (dim, head pair) instead of 3, no LDS
+//     reads for q (128 broadcast ds_read_b128 per chunk and wave before: the LDS pipe, shared by the CU, was the bound);
+//   * the K row is consumed in batches of 8 dims (no 128-register row copy): 67 KiB of LDS and < 128 VGPRs -> two
+//     workgroups per CU instead of one;
+//   * the softmax writes p = e * inv back to the score row (the same two roundings, layers.rs:503-505) and pads the row
+//     with +0.0 to a whole chunk; the V pass fetches p with s_load_dwordx8 and needs 2 VALU per (timestep, head):
+//     v_pk_mul_f32 (v[e], v[e+64]) * p, v_pk_add_f32 -- no v_readlane, no tail loop (o + 0.0 * v == o: o is never -0.0).
+// Scalar-cache coherence: q rows come from the previous launch, score rows from this wave's own vector stores ->
+// s_dcache_inv at entry and again (behind s_waitcnt vmcnt(0)) before the first scalar read of the rows.
+// ------------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v8f __attribute__((ext_vector_type(8)));
+typedef const float __attribute__((address_space(4))) kfloat;      // constant address space: uniform loads are s_load
+constexpr int kWaitLgkm0 = 0xc07f;                                 // s_waitcnt lgkmcnt(0) only (vmcnt 63, expcnt 7)
+__host__ __device__ inline size_t attn_pf2_smem_bytes() { return 4 * (2 * (size_t)kG2Tch * (kG2Hd + kKPad)) + 32 * 8; }
+
+template <int KVM, int NP>
+__global__ __launch_bounds__(64 * NP, NP / 2) void k_attn_pf2(const AttnArgs a0) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int hd = kG2Hd, kld = hd + kKPad, TCH = kG2Tch, TILE = TCH * kld;
+    constexpr int NTHR = 64 * NP, NSL = TCH * (hd / 4) / NTHR, NPR = KVM / 2;
+    float* tiles = (float*)smem_raw;                               // 2 x [TCH][kld]   (V: [TCH][hd])
+    unsigned long long* etab = (unsigned long long*)(tiles + 2 * TILE);
+    const int kvh = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pi0 = blockIdx.y * NP;
+    const int n_pos = a0.n_pos;
+    const int pi = min(pi0 + wave, n_pos - 1);
+    const bool live = pi0 + wave < n_pos;                          // wave-uniform
+    const size_t kvd = (size_t)a0.n_kv_heads * hd;
+    const int ast = a0.att_stride;
+    const int pos = __builtin_amdgcn_readfirstlane(a0.st[pi].pos);
+    const int pos_last = __builtin_amdgcn_readfirstlane(a0.st[min(pi0 + NP - 1, n_pos - 1)].pos);
+    const int np = pos + 1, np_max = pos_last + 1;
+    const float* kbase = a0.key_cache + (size_t)kvh * hd;
+    const float* vbase = a0.value_cache + (size_t)kvh * hd;
+    __builtin_amdgcn_s_dcache_inv();
+    if (tid < 32) etab[tid] = kExp2Tab[tid];
+
+    v4f sr[NSL];
+    auto issue = [&](const float* gbase, int t0) {
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) {
+            const int idx = tid + u * NTHR;
+            const int row = min(t0 + (idx >> 5), np_max - 1), c = idx & 31;
+            sr[u] = *(const v4f*)(gbase + (size_t)row * kvd + 4 * c);
+        }
+    };
+    auto commit = [&](float* tile, int ld) {
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) {
+            const int idx = tid + u * NTHR;
+            *(v4f*)(tile + (idx >> 5) * ld + 4 * (idx & 31)) = sr[u];
+        }
+    };
+    issue(kbase, 0);
+    const float scale = 1.0f / sqrtf((float)hd);                   // (head_dim as f32).sqrt().recip()
+    float* rows = a0.att_global + ((size_t)pi * a0.n_heads + (size_t)kvh * KVM) * ast;
+    // this position's KVM query rows, pair-interleaved: [pair][d][2]
+    kfloat* qk = (kfloat*)(unsigned long long)(a0.q_out + ((size_t)pi * a0.n_heads + (size_t)kvh * KVM) * hd);
+
+    // ---- scores: att[h][t] = (q_h . K[t]) * scale, one timestep per lane, a head PAIR per packed chain     layers.rs:391-401
+    for (int c0 = 0, it = 0; c0 < np_max; c0 += TCH, ++it) {
+        float* tile = tiles + (it & 1) * TILE;
+        commit(tile, kld);
+        __syncthreads();
+        if (c0 + TCH < np_max) issue(kbase, c0 + TCH);
+        if (live && c0 < np) {
+            const int t = c0 + lane;
+            const v4f* k4 = (const v4f*)(tile + lane * kld);
+            v2f d[NPR];
+#pragma unroll
+            for (int pr = 0; pr < NPR; ++pr) d[pr] = (v2f){-0.0f, -0.0f};
+            // software pipeline over batches of 8 dims: batch b+1's K float4s (LDS) and q pairs (scalar loads) are requested
+            // right after batch b's have landed, and travel under batch b's 32 packed operations
+            float qc[NPR][16], qn[NPR][16];
+            v4f kc[2], kn[2];
+            auto ldq = [&](float (&q)[NPR][16], int bb) {
+#pragma unroll
+                for (int pr = 0; pr < NPR; ++pr)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) q[pr][i] = qk[pr * 2 * hd + 16 * bb + i];
+            };
+            ldq(qc, 0);
+            kc[0] = k4[0]; kc[1] = k4[1];
+#pragma unroll
+            for (int b = 0; b < hd / 8; ++b) {
+                __builtin_amdgcn_s_waitcnt(kWaitLgkm0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (b + 1 < hd / 8) { ldq(qn, b + 1); kn[0] = k4[2 * b + 2]; kn[1] = k4[2 * b + 3]; }
+                __builtin_amdgcn_sched_barrier(0);
+                const float kk[8] = {kc[0].x, kc[0].y, kc[0].z, kc[0].w, kc[1].x, kc[1].y, kc[1].z, kc[1].w};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                    for (int pr = 0; pr < NPR; ++pr) {
+                        const v2f qq = {qc[pr][2 * i], qc[pr][2 * i + 1]};
+                        const v2f pp = qq * (v2f){kk[i], kk[i]};
+                        d[pr] = d[pr] + pp;
+                    }
+                }
+                // pure arithmetic is not ordered by sched_barrier: pin the chains to this stage
+                if constexpr (NPR == 2) asm volatile("" : "+v"(d[0]), "+v"(d[1]));
+                else asm volatile("" : "+v"(d[0]));
+                if (b + 1 < hd / 8) {
+#pragma unroll
+                    for (int pr = 0; pr < NPR; ++pr)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) qc[pr][i] = qn[pr][i];
+                    kc[0] = kn[0]; kc[1] = kn[1];
+                }
+            }
+            if (t < np) {
+#pragma unroll
+                for (int pr = 0; pr < NPR; ++pr) {
+                    rows[(size_t)(2 * pr) * ast + t] = d[pr].x * scale;
+                    rows[(size_t)(2 * pr + 1) * ast + t] = d[pr].y * scale;
+                }
+            }
+        }
+    }
+    __syncthreads();                                               // every wave is done with the K tiles
+    issue(vbase, 0);                                               // V chunk 0 travels under the softmax
+
+    // ---- softmax per (position, head) row (layers.rs:495-506): max, exp in place, exact sequential sum, p = e * inv in place;
+    // the row is padded with +0.0 to a whole chunk
+    if (live) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's score stores have landed (it reads them back)
+        const int np64 = (np + TCH - 1) & ~(TCH - 1);
+#pragma unroll 1
+        for (int h = 0; h < KVM; ++h) {
+            float* row = rows + (size_t)h * ast;
+            float m = -__builtin_inff();
+            for (int t = lane; t < np; t += 64) m = fmaxf(m, row[t]);
+            m = group_max_f32(m, 64);
+            for (int t0 = 0; t0 < np; t0 += 256) {                  // four exps per lane at a time (their f64 chains interleave)
+                float ev[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + 64 * u + lane;
+                    const float x = row[min(t, np - 1)];
+                    ev[u] = q3_expf_t(x - m, etab);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + 64 * u + lane;
+                    if (t < np) row[t] = ev[u];
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const float sum = row_exact_sum(row, np);
+            const float inv = 1.0f / sum;
+            for (int t = lane; t < np64; t += 64) {
+                const float e = row[min(t, np - 1)];
+                row[t] = (t < np) ? e * inv : 0.0f;                // layers.rs:503-505; +0.0 past the context
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the probabilities are in L2 ...
+        __builtin_amdgcn_s_dcache_inv();                           // ... and no scalar-cache line of these rows predates them
+    }
+
+    // ---- xb = sum_t att[t] * V[t]  (fill(0.0) then += in t order): elements (lane, lane + 64) of every head as one packed chain
+    v2f o[KVM];
+#pragma unroll
+    for (int h = 0; h < KVM; ++h) o[h] = (v2f){0.0f, 0.0f};
+    for (int c0 = 0, it = 0; c0 < np_max; c0 += TCH, ++it) {
+        float* tile = tiles + (it & 1) * TILE;
+        commit(tile, hd);
+        __syncthreads();
+        if (c0 + TCH < np_max) issue(vbase, c0 + TCH);
+        if (live && c0 < np) {
+            const float* v0 = tile + lane;
+            const float* prow = rows + c0;
+            v8f pc[KVM], pn[KVM];
+            v2f vc[8], vn[8];
+#pragma unroll
+            for (int h = 0; h < KVM; ++h)
+                asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(pc[h]) : "s"(prow + (size_t)h * ast) : "memory");
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vc[u] = (v2f){v0[u * hd], v0[u * hd + 64]};
+#pragma unroll
+            for (int tb = 0; tb < TCH; tb += 8) {
+                __builtin_amdgcn_s_waitcnt(kWaitLgkm0);            // this batch's probabilities (scalar) and V elements (LDS) have landed
+                __builtin_amdgcn_sched_barrier(0);
+                if (tb + 8 < TCH) {
+#pragma unroll
+                    for (int h = 0; h < KVM; ++h)
+                        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(pn[h]) : "s"(prow + (size_t)h * ast + tb + 8) : "memory");
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) vn[u] = (v2f){v0[(tb + 8 + u) * hd], v0[(tb + 8 + u) * hd + 64]};
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                    for (int h = 0; h < KVM; ++h) {
+                        const float p = pc[h][u];
+                        o[h] = o[h] + vc[u] * (v2f){p, p};
+                    }
+                }
+                if constexpr (KVM == 4) asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+                else asm volatile("" : "+v"(o[0]), "+v"(o[1]));
+                if (tb + 8 < TCH) {
+#pragma unroll
+                    for (int h = 0; h < KVM; ++h) pc[h] = pn[h];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) vc[u] = vn[u];
+                }
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int h = 0; h < KVM; ++h) {
+            const float oo[4] = {o[h].x, o[h].y, 0.0f, 0.0f};
+            gqa_store(a0, (size_t)pi, kvh * KVM + h, hd, lane, oo);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Batched prefill (T consecutive positions of ONE sequence per step, all sharing the engine's KV cache): the key
 // rows of the whole block must be in the cache before any position's attention runs, so QK-norm + RoPE of K
 // (layers.rs:346-372) gets its own small kernel.  grid (kv heads, positions), one wave each.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_knorm_rope(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[3 * 256];
-    const int hd = a.hd, kvh = blockIdx.x, lane = threadIdx.x;
+    const int hd = a.hd, lane = threadIdx.x;
     const size_t sbi = blockIdx.y;
     const int pos = a.st[sbi].pos;
-    const size_t kvd = (size_t)a.n_kv_heads * hd;
-    const float* ksrc = a.k_raw + sbi * a.sb_kraw + (size_t)kvh * hd;
     float* raw = lds, *sq = lds + hd, *dst = lds + 2 * hd;
     RopeRegs rr;
+    if ((int)blockIdx.x >= a.n_kv_heads) {
+        // query head (k_attn_pf2 only): normalised + rotated q goes to q_out, the two heads of a pair interleaved element by
+        // element ([position][pair][d][2]) so that the score loop fetches (q_h[d], q_h+1[d]) as one scalar pair
+        const int h = (int)blockIdx.x - a.n_kv_heads;
+        const float* qsrc = a.q + sbi * a.sb_q + (size_t)h * hd;
+        rope_regs_load(rr, a.q_norm_w, a.rope + (size_t)pos * hd, hd);
+        for (int i = lane; i < hd; i += 64) raw[i] = qsrc[i];
+        wave_lds_sync();
+        wave_norm_rope(dst, raw, sq, rr, hd, 1);
+        wave_lds_sync();
+        float* qrow = a.q_out + (sbi * a.n_heads + (size_t)(h & ~1)) * hd + (h & 1);
+        for (int i = lane; i < hd; i += 64) qrow[2 * i] = dst[i];
+        return;
+    }
+    const int kvh = blockIdx.x;
+    const size_t kvd = (size_t)a.n_kv_heads * hd;
+    const float* ksrc = a.k_raw + sbi * a.sb_kraw + (size_t)kvh * hd;
     rope_regs_load(rr, a.k_norm_w, a.rope + (size_t)pos * hd, hd);
     for (int i = lane; i < hd; i += 64) raw[i] = ksrc[i];
     wave_lds_sync();

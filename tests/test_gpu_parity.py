@@ -482,7 +482,7 @@ def test_batched_decode_long_positions(q3, tmp_path_factory):
 
 @pytest.mark.parametrize("shape_name,n_prompt,first_pos", [("tiny-g64", 41, 0), ("small-hd128", 70, 3), ("small-longctx", 333, 0)])
 def test_batched_prefill_is_sequential_equivalent(q3, shape_name, n_prompt, first_pos, tmp_path_factory):
-    """q3_prefill_batched (32 positions per weight pass, shared KV cache) == q3_prefill == the prompt loop of `chat`
+    """q3_prefill_batched (up to 256 positions per weight pass, shared KV cache) == q3_prefill == the prompt loop of `chat`
     (generation.rs:116-123): bit-identical cache rows, same first generated token, same continuation."""
     ck = q3.checkpoint
     shape = ck.SHAPES[shape_name]
@@ -506,6 +506,32 @@ def test_batched_prefill_is_sequential_equivalent(q3, shape_name, n_prompt, firs
         assert out.shape == (2, 3)
         with pytest.raises(IndexError):
             t.prefill([1, 2, 10 ** 7], 0, batched=True)
+
+
+@pytest.mark.parametrize("shape_name", ["small-longctx", "qwen3-0.6b-dims-l2"])      # head_dim 64 (k_attn_gqa) / 128 (k_attn_pf)
+@pytest.mark.parametrize("block", [32, 48, 128, 256])
+def test_batched_prefill_block_sizes_agree(q3, block, shape_name, tmp_path_factory, monkeypatch):
+    """Q3_PREFILL_M picks the positions per weight pass: 32 = the batch-32 kernels (k_bgemm + LDS term tile), larger blocks
+    the dense kernels (k_pgemm in-lane fold, k_attn_pf).  Every block size must give the cache rows and tokens of the
+    sequential prompt loop (generation.rs:116-123) bit for bit, including a ragged last block and a non-zero start."""
+    ck = q3.checkpoint
+    shape = ck.SHAPES[shape_name]
+    path = str(tmp_path_factory.mktemp("preb") / "m.bin")
+    ck.write_synthetic_checkpoint(path, shape, seed=321)
+    prompt = ck.iter_prompt_tokens(shape, 9, 301)
+    with q3.TransformerBuilder(path).with_ctx_length(512).build() as t:
+        t.prefill(prompt[:5], 0)                      # positions 0..4 by the sequential path in both runs
+        want_first = t.prefill(prompt[5:], 5)
+        want_rest = t.generate_greedy(want_first, len(prompt), 5)
+        want_k, want_v = t.read_state("key"), t.read_state("value")
+    monkeypatch.setenv("Q3_PREFILL_M", str(block))
+    with q3.TransformerBuilder(path).with_ctx_length(512).build() as t:
+        t.prefill(prompt[:5], 0)
+        got_first = t.prefill(prompt[5:], 5, batched=True)
+        assert got_first == want_first
+        assert t.generate_greedy(got_first, len(prompt), 5) == want_rest
+        assert_biteq(t.read_state("key"), want_k, f"key cache, block {block}")
+        assert_biteq(t.read_state("value"), want_v, f"value cache, block {block}")
 
 
 def test_batched_prefill_kv_and_token_vs_oracle(q3, oracle, tmp_path_factory):
