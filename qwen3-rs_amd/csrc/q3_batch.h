@@ -1432,6 +1432,7 @@ __global__ __launch_bounds__(64 * NP, NP / 2) void k_attn_pf2(const AttnArgs a0)
     const int np = pos + 1, np_max = pos_last + 1;
     const float* kbase = a0.key_cache + (size_t)kvh * hd;
     const float* vbase = a0.value_cache + (size_t)kvh * hd;
+    GQA_STAMP(0);
     __builtin_amdgcn_s_dcache_inv();
     if (tid < 32) etab[tid] = kExp2Tab[tid];
 
@@ -1458,10 +1459,15 @@ __global__ __launch_bounds__(64 * NP, NP / 2) void k_attn_pf2(const AttnArgs a0)
     kfloat* qk = (kfloat*)(unsigned long long)(a0.q_out + ((size_t)pi * a0.n_heads + (size_t)kvh * KVM) * hd);
 
     // ---- scores: att[h][t] = (q_h . K[t]) * scale, one timestep per lane, a head PAIR per packed chain     layers.rs:391-401
+    float mx[KVM];
+#pragma unroll
+    for (int h = 0; h < KVM; ++h) mx[h] = -__builtin_inff();
     for (int c0 = 0, it = 0; c0 < np_max; c0 += TCH, ++it) {
         float* tile = tiles + (it & 1) * TILE;
+        if (it == 8) GQA_STAMP(8);
         commit(tile, kld);
         __syncthreads();
+        if (it == 8) GQA_STAMP(9);
         if (c0 + TCH < np_max) issue(kbase, c0 + TCH);
         if (live && c0 < np) {
             const int t = c0 + lane;
@@ -1508,20 +1514,26 @@ __global__ __launch_bounds__(64 * NP, NP / 2) void k_attn_pf2(const AttnArgs a0)
                     kc[0] = kn[0]; kc[1] = kn[1];
                 }
             }
+            if (it == 8) GQA_STAMP(10);
             if (t < np) {
 #pragma unroll
                 for (int pr = 0; pr < NPR; ++pr) {
-                    rows[(size_t)(2 * pr) * ast + t] = d[pr].x * scale;
-                    rows[(size_t)(2 * pr + 1) * ast + t] = d[pr].y * scale;
+                    const float s0 = d[pr].x * scale, s1 = d[pr].y * scale;
+                    rows[(size_t)(2 * pr) * ast + t] = s0;
+                    rows[(size_t)(2 * pr + 1) * ast + t] = s1;
+                    mx[2 * pr] = fmaxf(mx[2 * pr], s0);            // running row maxima stay in registers (no pass over the row)
+                    mx[2 * pr + 1] = fmaxf(mx[2 * pr + 1], s1);
                 }
             }
         }
     }
+    GQA_STAMP(1);
     __syncthreads();                                               // every wave is done with the K tiles
     issue(vbase, 0);                                               // V chunk 0 travels under the softmax
 
     // ---- softmax per (position, head) row (layers.rs:495-506): max, exp in place, exact sequential sum, p = e * inv in place;
-    // the row is padded with +0.0 to a whole chunk
+    // the row is padded with +0.0 to a whole chunk.  The passes over the row are latency-bound at two waves per SIMD: every
+    // step requests the next step's values before it works on its own.
     if (live) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's score stores have landed (it reads them back)
@@ -1529,43 +1541,56 @@ __global__ __launch_bounds__(64 * NP, NP / 2) void k_attn_pf2(const AttnArgs a0)
 #pragma unroll 1
         for (int h = 0; h < KVM; ++h) {
             float* row = rows + (size_t)h * ast;
-            float m = -__builtin_inff();
-            for (int t = lane; t < np; t += 64) m = fmaxf(m, row[t]);
-            m = group_max_f32(m, 64);
-            for (int t0 = 0; t0 < np; t0 += 256) {                  // four exps per lane at a time (their f64 chains interleave)
-                float ev[4];
+            const float m = group_max_f32(mx[h], 64);
+            {   // four exps per lane and step (their f64 chains interleave)
+                float xc[4], xn[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int t = t0 + 64 * u + lane;
-                    const float x = row[min(t, np - 1)];
-                    ev[u] = q3_expf_t(x - m, etab);
-                }
+                for (int u = 0; u < 4; ++u) xc[u] = row[min(64 * u + lane, np - 1)];
+#pragma unroll 1
+                for (int t0 = 0; t0 < np; t0 += 256) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int t = t0 + 64 * u + lane;
-                    if (t < np) row[t] = ev[u];
+                    for (int u = 0; u < 4; ++u) xn[u] = row[min(t0 + 256 + 64 * u + lane, np - 1)];
+                    float ev[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) ev[u] = q3_expf_t(xc[u] - m, etab);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int t = t0 + 64 * u + lane;
+                        if (t < np) row[t] = ev[u];
+                        xc[u] = xn[u];
+                    }
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const float sum = row_exact_sum(row, np);
             const float inv = 1.0f / sum;
-            for (int t = lane; t < np64; t += 64) {
-                const float e = row[min(t, np - 1)];
-                row[t] = (t < np) ? e * inv : 0.0f;                // layers.rs:503-505; +0.0 past the context
+#pragma unroll 1
+            for (int t0 = 0; t0 < np64; t0 += 512) {               // layers.rs:503-505; +0.0 past the context
+                float e[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) e[u] = row[min(t0 + 64 * u + lane, np - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = t0 + 64 * u + lane;
+                    if (t < np64) row[t] = (t < np) ? e[u] * inv : 0.0f;
+                }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the probabilities are in L2 ...
         __builtin_amdgcn_s_dcache_inv();                           // ... and no scalar-cache line of these rows predates them
     }
 
+    GQA_STAMP(2);
     // ---- xb = sum_t att[t] * V[t]  (fill(0.0) then += in t order): elements (lane, lane + 64) of every head as one packed chain
     v2f o[KVM];
 #pragma unroll
     for (int h = 0; h < KVM; ++h) o[h] = (v2f){0.0f, 0.0f};
     for (int c0 = 0, it = 0; c0 < np_max; c0 += TCH, ++it) {
         float* tile = tiles + (it & 1) * TILE;
+        if (it == 8) GQA_STAMP(11);
         commit(tile, hd);
         __syncthreads();
+        if (it == 8) GQA_STAMP(12);
         if (c0 + TCH < np_max) issue(vbase, c0 + TCH);
         if (live && c0 < np) {
             const float* v0 = tile + lane;
@@ -1606,8 +1631,10 @@ __global__ __launch_bounds__(64 * NP, NP / 2) void k_attn_pf2(const AttnArgs a0)
                     for (int u = 0; u < 8; ++u) vc[u] = vn[u];
                 }
             }
+            if (it == 8) GQA_STAMP(13);
         }
     }
+    GQA_STAMP(3);
     if (live) {
 #pragma unroll
         for (int h = 0; h < KVM; ++h) {
@@ -1615,6 +1642,7 @@ __global__ __launch_bounds__(64 * NP, NP / 2) void k_attn_pf2(const AttnArgs a0)
             gqa_store(a0, (size_t)pi, kvh * KVM + h, hd, lane, oo);
         }
     }
+    GQA_STAMP(4);
 }
 
 // ------------------------------------------------------------------------------------------------
