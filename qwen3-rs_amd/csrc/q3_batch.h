@@ -442,6 +442,7 @@ __global__ __launch_bounds__(kBThreads) void k_bgemm(const BGemmArgs a) {
 // requested two groups ahead: the same 1 KiB-per-wave contiguous loads of the packed layout as k_bgemm.
 // ------------------------------------------------------------------------------------------------
 constexpr int kPgThreads = 256;
+typedef float pk2 __attribute__((ext_vector_type(2)));
 template <int EPI, int RT, int PT, int DEPTH = 4>
 __global__ __launch_bounds__(kPgThreads) void k_pgemm(const BGemmArgs a) {
     static_assert(EPI != EPI_SWIGLU || (RT % 2) == 0, "SwiGLU tasks hold w1 tiles and their w3 tiles");
@@ -461,13 +462,16 @@ __global__ __launch_bounds__(kPgThreads) void k_pgemm(const BGemmArgs a) {
     for (int task = blockIdx.x * (kPgThreads / 64) + wave; task < ntasks; task += gridDim.x * (kPgThreads / 64)) {
         const int rtask = task / npg, pg = task - rtask * npg;
         const v4i* wp[RT];
-        const v4f* wsp[RT];
+        const float* wsp[RT];
         const v4i* xp[PT];
         const float* xsp[PT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             wp[rt] = (const v4i*)a.wq + (size_t)(rtask * RT + rt) * tile_v4 + lane;
-            wsp[rt] = (const v4f*)a.ws + (size_t)(rtask * RT + rt) * ng * 4 + q;
+            // one scale dword per lane: lane (q, s) fetches the scale of row 4q + (s & 3) and the four rows of its accumulators
+            // come from lanes 16q + 0..3 by DPP row broadcast.  (A v4f per lane moved 1 KiB through the L1 return path for
+            // 64 B of scales: with the fragments that path, not the VALU or the matrix core, bounded the kernel.)
+            wsp[rt] = a.ws + (size_t)(rtask * RT + rt) * ng * 16 + 4 * q + (s & 3);
         }
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(kPgThreads) void k_pgemm(const BGemmArgs a) {
             xsp[pt] = a.xs + (size_t)ptile * ng * 16 + s;
         }
         v4i fa[DA][RT], fb[DB][PT];
-        v4f fws[DA][RT];
+        float fws[DA][RT];
         float fxs[DB][PT];
         auto load_a = [&](int slot, int g) {
             const int gg = min(g, ng - 1);
@@ -486,7 +490,7 @@ __global__ __launch_bounds__(kPgThreads) void k_pgemm(const BGemmArgs a) {
                 // weight lines through L1 / L2 -- with non-temporal loads every position group fetched the tile from HBM again
                 // (r03 sweep: w1|w3 time followed the number of position groups, 46 / 46 / 63 us for 2 / 4 / 8 groups)
                 fa[slot][rt] = wp[rt][(size_t)gg * 64];
-                fws[slot][rt] = wsp[rt][(size_t)gg * 4];
+                fws[slot][rt] = wsp[rt][(size_t)gg * 16];
             }
         };
         auto load_b = [&](int slot, int g) {
@@ -504,38 +508,65 @@ __global__ __launch_bounds__(kPgThreads) void k_pgemm(const BGemmArgs a) {
             for (int pt = 0; pt < PT; ++pt) acc[rt][pt] = (v4f){-0.0f, -0.0f, -0.0f, -0.0f};     // Iterator::sum::<f32>() identity
 #pragma unroll
         for (int d = 0; d < DA - 1; ++d) { load_a(d, d); load_b(d, d); }
-        auto fold_group = [&](int slot) {
+        // A group's work is split in two so that the matrix core and the VALU overlap: mfma_group(g + 1) is issued, then the
+        // convert / scale / ordered-add chain of group g runs while those MFMAs execute (one wave per SIMD here: a chain that
+        // starts right behind its own MFMA waits out the whole MFMA latency -- s_nop 7 in the r03 disassembly -- four times a group).
+        v4i cc[RT][PT], cn[RT][PT];
+        auto mfma_group = [&](v4i (&c)[RT][PT], int slot) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+                    c[rt][pt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[slot][rt], fb[slot][pt], (v4i){0, 0, 0, 0}, 0, 0, 0);
+        };
+        auto math_group = [&](const v4i (&cg)[RT][PT], int slot) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const v4f wsv = fws[slot][rt];
+                const int wsr = __float_as_int(fws[slot][rt]);
+                v4f wsv;                                           // rows 4q .. 4q+3: v_mov_b32_dpp row_newbcast:0..3
+                wsv.x = __int_as_float(__builtin_amdgcn_mov_dpp(wsr, 0x150, 0xf, 0xf, true));
+                wsv.y = __int_as_float(__builtin_amdgcn_mov_dpp(wsr, 0x151, 0xf, 0xf, true));
+                wsv.z = __int_as_float(__builtin_amdgcn_mov_dpp(wsr, 0x152, 0xf, 0xf, true));
+                wsv.w = __int_as_float(__builtin_amdgcn_mov_dpp(wsr, 0x153, 0xf, 0xf, true));
 #pragma unroll
                 for (int pt = 0; pt < PT; ++pt) {
-                    const v4i c = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[slot][rt], fb[slot][pt], (v4i){0, 0, 0, 0}, 0, 0, 0);
+                    const v4i c = cg[rt][pt];
                     const float xsc = fxs[slot][pt];
-                    // tensor.rs:59  ((dot as f32) * ws) * xs.  Every product passes through an opaque register: plain -O3
-                    // SLP-packs the four lanes into v_pk_mul / v_pk_add, whose operand PAIRS forced register copies of
-                    // in-flight ring slots at the loop head -- each copy a wait for a load issued that same iteration
-                    // (r03 disassembly: s_waitcnt vmcnt(4) with 32 loads in the ring)
-                    float t0 = (float)c.x * wsv.x, t1 = (float)c.y * wsv.y, t2 = (float)c.z * wsv.z, t3 = (float)c.w * wsv.w;
-                    asm("" : "+v"(t0)); asm("" : "+v"(t1)); asm("" : "+v"(t2)); asm("" : "+v"(t3));
-                    t0 = t0 * xsc; t1 = t1 * xsc; t2 = t2 * xsc; t3 = t3 * xsc;
-                    asm("" : "+v"(t0)); asm("" : "+v"(t1)); asm("" : "+v"(t2)); asm("" : "+v"(t3));
+                    // tensor.rs:59  ((dot as f32) * ws) * xs, then the g-ascending add.  The pairs are chosen by hand -- (rows 4q,
+                    // 4q+1) and (4q+2, 4q+3) of one (row tile, position tile): their scales are the two halves of the v4f the ring
+                    // loaded, xs is broadcast by op_sel -- three packed operations per pair.  Every value passes through an opaque
+                    // register so that the SLP vectoriser does not re-pair them across tiles (its pairs forced copies of in-flight
+                    // ring slots: s_waitcnt vmcnt(4) with 32 loads in the ring).
+                    pk2 t01 = (pk2){(float)c.x, (float)c.y} * (pk2){wsv.x, wsv.y};
+                    pk2 t23 = (pk2){(float)c.z, (float)c.w} * (pk2){wsv.z, wsv.w};
+                    asm("" : "+v"(t01)); asm("" : "+v"(t23));
+                    t01 = t01 * (pk2){xsc, xsc}; t23 = t23 * (pk2){xsc, xsc};
+                    asm("" : "+v"(t01)); asm("" : "+v"(t23));
                     v4f& ac = acc[rt][pt];
-                    float a0 = ac.x + t0, a1 = ac.y + t1, a2 = ac.z + t2, a3 = ac.w + t3;
-                    asm("" : "+v"(a0)); asm("" : "+v"(a1)); asm("" : "+v"(a2)); asm("" : "+v"(a3));
-                    ac.x = a0; ac.y = a1; ac.z = a2; ac.w = a3;
+                    pk2 a01 = (pk2){ac.x, ac.y} + t01, a23 = (pk2){ac.z, ac.w} + t23;
+                    asm("" : "+v"(a01)); asm("" : "+v"(a23));
+                    ac.x = a01.x; ac.y = a01.y; ac.z = a23.x; ac.w = a23.y;
                 }
             }
         };
+        auto rotate = [&]() {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) cc[rt][pt] = cn[rt][pt];
+        };
         // main loop: whole rings of DA groups, NO branch inside (a wave-uniform `if (g < ng)` here split the body into basic
         // blocks and hipcc closed each with s_waitcnt vmcnt(0): every load was waited for in the iteration that issued it)
+        mfma_group(cc, 0);
         int g0 = 0;
         for (; g0 + DA <= ng; g0 += DA) {
 #pragma unroll
             for (int u = 0; u < DA; ++u) {
                 load_a((u + DA - 1) % DA, g0 + u + DA - 1);      // (clamped to the row: the last ring re-reads its last group)
                 load_b((u + DB - 1) % DB, g0 + u + DB - 1);
-                fold_group(u);
+                mfma_group(cn, (u + 1) % DA);                    // group g + 1 (past the row: a re-read group, its result is dropped)
+                math_group(cc, u);
+                rotate();
                 // stage boundary pinned: without it hipcc hoists the four stages' MFMAs to the top of the body behind one
                 // s_waitcnt vmcnt(0) and issues all sixteen loads as one burst behind them -- no load is in flight across a stage
                 __builtin_amdgcn_sched_barrier(0);
@@ -544,7 +575,11 @@ __global__ __launch_bounds__(kPgThreads) void k_pgemm(const BGemmArgs a) {
         // tail: ng % DA groups, already in the ring
 #pragma unroll
         for (int u = 0; u < DA - 1; ++u)
-            if (g0 + u < ng) fold_group(u);
+            if (g0 + u < ng) {
+                if (u + 1 < DA - 1) mfma_group(cn, u + 1);
+                math_group(cc, u);
+                rotate();
+            }
         // ---- epilogue: lane (s, q) owns out[position pg*PT*16 + pt*16 + s][rows 4q .. 4q+3 of each row tile]
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {

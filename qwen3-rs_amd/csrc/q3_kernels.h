@@ -1504,7 +1504,9 @@ __device__ __forceinline__ void stage_issue(StageRegs& sr, const float* gbase, s
     const int q4s = __builtin_ctz(hd >> 2);            // hd is a power of two: float4 per row = 1 << q4s
     const int rps = kWG >> q4s;                         // rows covered by one slot of the whole workgroup
     const int r0 = (int)threadIdx.x >> q4s, c = (int)threadIdx.x & ((1 << q4s) - 1);
-    const float* p = gbase + (size_t)(t0 + r0) * kvd + 4 * c;
+    // threads whose first row lies past the chunk (tiny head_dim: 128 rows per slot) re-read the chunk's last row: their
+    // own row may lie past the end of the cache allocation
+    const float* p = gbase + (size_t)(t0 + min(r0, max(cnt - 1, 0))) * kvd + 4 * c;
     const size_t stride = (size_t)rps * kvd;
 #pragma unroll
     for (int u = 0; u < kStageSlots; ++u) {
