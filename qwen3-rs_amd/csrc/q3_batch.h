@@ -1425,46 +1425,55 @@ __global__ __launch_bounds__(64 * NP) void k_attn_pf(const AttnArgs a0) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_attn_pf2: k_attn_pf with the wave-uniform operands in SCALAR registers.  Same work split (one workgroup per kv head x NP
-// consecutive positions, wave = position, K / V chunks staged in LDS once for NP x KVM query rows), same arithmetic and order,
-// but
+// k_attn_pf2: k_attn_pf with the wave-uniform operands in SCALAR registers and one wave per (position, head PAIR).
+// One workgroup per kv head x NP consecutive positions; the K / V chunks (64 timesteps) are staged in LDS once for its
+// NP x KVM query rows; wave w owns position w / (KVM/2) and the two query heads of pair w % (KVM/2) -- 16 waves for
+// Qwen3-4B/8B (four per SIMD: the latency of one wave's scalar loads, barriers and softmax passes is another wave's
+// issue slot; with one wave per position the kernel ran two per SIMD and waited half of the time).  Arithmetic and order per
+// (head, position) are those of k_attn_pf / k_attn / the reference (layers.rs:346-419,495-506): bit-identical results.
 //   * q is normalised + rotated by k_knorm_rope (one launch for the block's K and q heads) and stored pair-interleaved; the
-//     score loop reads it with s_load (constant address space) and forms TWO heads' products with one v_pk_mul_f32
-//     (K element broadcast) and extends TWO chains with one v_pk_add_f32: 2 VALU per (dim, head pair) instead of 3, no LDS
-//     reads for q (128 broadcast ds_read_b128 per chunk and wave before: the LDS pipe, shared by the CU, was the bound);
-//   * the K row is consumed in batches of 8 dims (no 128-register row copy): 67 KiB of LDS and < 128 VGPRs -> two
-//     workgroups per CU instead of one;
-//   * the softmax writes p = e * inv back to the score row (the same two roundings, layers.rs:503-505) and pads the row
-//     with +0.0 to a whole chunk; the V pass fetches p with s_load_dwordx8 and needs 2 VALU per (timestep, head):
-//     v_pk_mul_f32 (v[e], v[e+64]) * p, v_pk_add_f32 -- no v_readlane, no tail loop (o + 0.0 * v == o: o is never -0.0).
+//     score loop reads it with s_load (constant address space) and forms the two heads' products with one v_pk_mul_f32
+//     (K element broadcast by op_sel) and extends the two chains with one v_pk_add_f32: 2 VALU per dim and pair, no LDS
+//     reads for q.  The K row is consumed in batches of 16 dims (no 128-register row copy);
+//   * the row maxima accumulate in registers during the score loop; the softmax writes p = e * inv back to the score row
+//     (the same two roundings, layers.rs:503-505) and pads it with +0.0 to a whole chunk; the V pass fetches p with
+//     s_load_dwordx16 and needs 2 VALU per (timestep, head): v_pk_mul_f32 (v[e], v[e+64]) * p, v_pk_add_f32 -- no
+//     v_readlane, no tail loop (o + 0.0 * v == o: o is never -0.0);
+//   * both loops are software pipelines pinned with sched_barrier: [operands of this stage have landed][request the next
+//     stage's][this stage's 32 packed operations]; scalar loads return out of order, so the only usable wait is lgkmcnt(0)
+//     and a stage is one request deep.
 // Scalar-cache coherence: q rows come from the previous launch, score rows from this wave's own vector stores ->
 // s_dcache_inv at entry and again (behind s_waitcnt vmcnt(0)) before the first scalar read of the rows.
 // ------------------------------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v8f __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 typedef const float __attribute__((address_space(4))) kfloat;      // constant address space: uniform loads are s_load
 constexpr int kWaitLgkm0 = 0xc07f;                                 // s_waitcnt lgkmcnt(0) only (vmcnt 63, expcnt 7)
 __host__ __device__ inline size_t attn_pf2_smem_bytes() { return 4 * (2 * (size_t)kG2Tch * (kG2Hd + kKPad)) + 32 * 8; }
+__host__ __device__ constexpr int attn_pf2_threads(int kvm, int np) { return 64 * np * (kvm / 2); }
 
 template <int KVM, int NP>
-__global__ __launch_bounds__(64 * NP, NP / 2) void k_attn_pf2(const AttnArgs a0) {
+__global__ __launch_bounds__(64 * NP * (KVM / 2), NP * (KVM / 2) / 4) void k_attn_pf2(const AttnArgs a0) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int hd = kG2Hd, kld = hd + kKPad, TCH = kG2Tch, TILE = TCH * kld;
-    constexpr int NTHR = 64 * NP, NSL = TCH * (hd / 4) / NTHR, NPR = KVM / 2;
+    constexpr int NPRW = KVM / 2, NW = NP * NPRW, NTHR = 64 * NW, NSL = TCH * (hd / 4) / NTHR;
+    constexpr int DS = 16, TS = 16;                                // dims per score stage, timesteps per V stage
+    static_assert(NSL >= 1 && hd % DS == 0 && TCH % TS == 0, "");
     float* tiles = (float*)smem_raw;                               // 2 x [TCH][kld]   (V: [TCH][hd])
     unsigned long long* etab = (unsigned long long*)(tiles + 2 * TILE);
     const int kvh = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pw = wave / NPRW, pr = wave - pw * NPRW;             // position within the workgroup, head pair within the kv group
     const int pi0 = blockIdx.y * NP;
     const int n_pos = a0.n_pos;
-    const int pi = min(pi0 + wave, n_pos - 1);
-    const bool live = pi0 + wave < n_pos;                          // wave-uniform
+    const int pi = min(pi0 + pw, n_pos - 1);
+    const bool live = pi0 + pw < n_pos;                            // wave-uniform
     const size_t kvd = (size_t)a0.n_kv_heads * hd;
     const int ast = a0.att_stride;
     const int pos = __builtin_amdgcn_readfirstlane(a0.st[pi].pos);
     const int pos_last = __builtin_amdgcn_readfirstlane(a0.st[min(pi0 + NP - 1, n_pos - 1)].pos);
-    const int np = pos + 1, np_max = pos_last + 1;
+    const int np = pos + 1, np_max = pos_last + 1;                 // positions of a block are consecutive and ascending
     const float* kbase = a0.key_cache + (size_t)kvh * hd;
     const float* vbase = a0.value_cache + (size_t)kvh * hd;
     GQA_STAMP(0);
@@ -1489,14 +1498,13 @@ __global__ __launch_bounds__(64 * NP, NP / 2) void k_attn_pf2(const AttnArgs a0)
     };
     issue(kbase, 0);
     const float scale = 1.0f / sqrtf((float)hd);                   // (head_dim as f32).sqrt().recip()
-    float* rows = a0.att_global + ((size_t)pi * a0.n_heads + (size_t)kvh * KVM) * ast;
-    // this position's KVM query rows, pair-interleaved: [pair][d][2]
-    kfloat* qk = (kfloat*)(unsigned long long)(a0.q_out + ((size_t)pi * a0.n_heads + (size_t)kvh * KVM) * hd);
+    const int head0 = kvh * KVM + 2 * pr;                          // this wave's heads: head0, head0 + 1
+    float* rows = a0.att_global + ((size_t)pi * a0.n_heads + (size_t)head0) * ast;       // score rows: rows, rows + ast
+    // the pair's query rows, interleaved element by element: [d][2]
+    kfloat* qk = (kfloat*)(unsigned long long)(a0.q_out + ((size_t)pi * a0.n_heads + (size_t)head0) * hd);
 
-    // ---- scores: att[h][t] = (q_h . K[t]) * scale, one timestep per lane, a head PAIR per packed chain     layers.rs:391-401
-    float mx[KVM];
-#pragma unroll
-    for (int h = 0; h < KVM; ++h) mx[h] = -__builtin_inff();
+    // ---- scores: att[h][t] = (q_h . K[t]) * scale, one timestep per lane, the head pair as one packed chain   layers.rs:391-401
+    float mx0 = -__builtin_inff(), mx1 = -__builtin_inff();
     for (int c0 = 0, it = 0; c0 < np_max; c0 += TCH, ++it) {
         float* tile = tiles + (it & 1) * TILE;
         if (it == 8) GQA_STAMP(8);
@@ -1507,58 +1515,50 @@ __global__ __launch_bounds__(64 * NP, NP / 2) void k_attn_pf2(const AttnArgs a0)
         if (live && c0 < np) {
             const int t = c0 + lane;
             const v4f* k4 = (const v4f*)(tile + lane * kld);
-            v2f d[NPR];
+            v2f d = {-0.0f, -0.0f};
+            float qc[2 * DS], qn[2 * DS];
+            v4f kc[DS / 4], kn[DS / 4];
+            auto ldq = [&](float (&q)[2 * DS], int bb) {
 #pragma unroll
-            for (int pr = 0; pr < NPR; ++pr) d[pr] = (v2f){-0.0f, -0.0f};
-            // software pipeline over batches of 8 dims: batch b+1's K float4s (LDS) and q pairs (scalar loads) are requested
-            // right after batch b's have landed, and travel under batch b's 32 packed operations
-            float qc[NPR][16], qn[NPR][16];
-            v4f kc[2], kn[2];
-            auto ldq = [&](float (&q)[NPR][16], int bb) {
-#pragma unroll
-                for (int pr = 0; pr < NPR; ++pr)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) q[pr][i] = qk[pr * 2 * hd + 16 * bb + i];
+                for (int i = 0; i < 2 * DS; ++i) q[i] = qk[2 * DS * bb + i];
             };
             ldq(qc, 0);
-            kc[0] = k4[0]; kc[1] = k4[1];
 #pragma unroll
-            for (int b = 0; b < hd / 8; ++b) {
+            for (int j = 0; j < DS / 4; ++j) kc[j] = k4[j];
+#pragma unroll
+            for (int b = 0; b < hd / DS; ++b) {
                 __builtin_amdgcn_s_waitcnt(kWaitLgkm0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (b + 1 < hd / 8) { ldq(qn, b + 1); kn[0] = k4[2 * b + 2]; kn[1] = k4[2 * b + 3]; }
+                if (b + 1 < hd / DS) {
+                    ldq(qn, b + 1);
+#pragma unroll
+                    for (int j = 0; j < DS / 4; ++j) kn[j] = k4[(DS / 4) * (b + 1) + j];
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                const float kk[8] = {kc[0].x, kc[0].y, kc[0].z, kc[0].w, kc[1].x, kc[1].y, kc[1].z, kc[1].w};
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int j = 0; j < DS / 4; ++j) {
+                    const float kk[4] = {kc[j].x, kc[j].y, kc[j].z, kc[j].w};
 #pragma unroll
-                    for (int pr = 0; pr < NPR; ++pr) {
-                        const v2f qq = {qc[pr][2 * i], qc[pr][2 * i + 1]};
-                        const v2f pp = qq * (v2f){kk[i], kk[i]};
-                        d[pr] = d[pr] + pp;
+                    for (int i = 0; i < 4; ++i) {
+                        const v2f qq = {qc[8 * j + 2 * i], qc[8 * j + 2 * i + 1]};
+                        d = d + qq * (v2f){kk[i], kk[i]};
                     }
                 }
-                // pure arithmetic is not ordered by sched_barrier: pin the chains to this stage
-                if constexpr (NPR == 2) asm volatile("" : "+v"(d[0]), "+v"(d[1]));
-                else asm volatile("" : "+v"(d[0]));
-                if (b + 1 < hd / 8) {
+                asm volatile("" : "+v"(d));                        // pure arithmetic is not ordered by sched_barrier: pin the chain to its stage
+                if (b + 1 < hd / DS) {
 #pragma unroll
-                    for (int pr = 0; pr < NPR; ++pr)
+                    for (int i = 0; i < 2 * DS; ++i) qc[i] = qn[i];
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) qc[pr][i] = qn[pr][i];
-                    kc[0] = kn[0]; kc[1] = kn[1];
+                    for (int j = 0; j < DS / 4; ++j) kc[j] = kn[j];
                 }
             }
             if (it == 8) GQA_STAMP(10);
             if (t < np) {
-#pragma unroll
-                for (int pr = 0; pr < NPR; ++pr) {
-                    const float s0 = d[pr].x * scale, s1 = d[pr].y * scale;
-                    rows[(size_t)(2 * pr) * ast + t] = s0;
-                    rows[(size_t)(2 * pr + 1) * ast + t] = s1;
-                    mx[2 * pr] = fmaxf(mx[2 * pr], s0);            // running row maxima stay in registers (no pass over the row)
-                    mx[2 * pr + 1] = fmaxf(mx[2 * pr + 1], s1);
-                }
+                const float s0 = d.x * scale, s1 = d.y * scale;
+                rows[t] = s0;
+                rows[(size_t)ast + t] = s1;
+                mx0 = fmaxf(mx0, s0);                              // running row maxima stay in registers (no pass over the row)
+                mx1 = fmaxf(mx1, s1);
             }
         }
     }
@@ -1567,16 +1567,16 @@ __global__ __launch_bounds__(64 * NP, NP / 2) void k_attn_pf2(const AttnArgs a0)
     issue(vbase, 0);                                               // V chunk 0 travels under the softmax
 
     // ---- softmax per (position, head) row (layers.rs:495-506): max, exp in place, exact sequential sum, p = e * inv in place;
-    // the row is padded with +0.0 to a whole chunk.  The passes over the row are latency-bound at two waves per SIMD: every
-    // step requests the next step's values before it works on its own.
+    // the row is padded with +0.0 to a whole chunk.  Every step of a pass requests the next step's values before it works on
+    // its own.
     if (live) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's score stores have landed (it reads them back)
         const int np64 = (np + TCH - 1) & ~(TCH - 1);
 #pragma unroll 1
-        for (int h = 0; h < KVM; ++h) {
+        for (int h = 0; h < 2; ++h) {
             float* row = rows + (size_t)h * ast;
-            const float m = group_max_f32(mx[h], 64);
+            const float m = group_max_f32(h ? mx1 : mx0, 64);
             {   // four exps per lane and step (their f64 chains interleave)
                 float xc[4], xn[4];
 #pragma unroll
@@ -1616,10 +1616,8 @@ __global__ __launch_bounds__(64 * NP, NP / 2) void k_attn_pf2(const AttnArgs a0)
     }
 
     GQA_STAMP(2);
-    // ---- xb = sum_t att[t] * V[t]  (fill(0.0) then += in t order): elements (lane, lane + 64) of every head as one packed chain
-    v2f o[KVM];
-#pragma unroll
-    for (int h = 0; h < KVM; ++h) o[h] = (v2f){0.0f, 0.0f};
+    // ---- xb = sum_t att[t] * V[t]  (fill(0.0) then += in t order): elements (lane, lane + 64) of a head as one packed chain
+    v2f o0 = {0.0f, 0.0f}, o1 = {0.0f, 0.0f};
     for (int c0 = 0, it = 0; c0 < np_max; c0 += TCH, ++it) {
         float* tile = tiles + (it & 1) * TILE;
         if (it == 8) GQA_STAMP(11);
@@ -1630,40 +1628,34 @@ __global__ __launch_bounds__(64 * NP, NP / 2) void k_attn_pf2(const AttnArgs a0)
         if (live && c0 < np) {
             const float* v0 = tile + lane;
             const float* prow = rows + c0;
-            v8f pc[KVM], pn[KVM];
-            v2f vc[8], vn[8];
+            v16f pc0, pc1, pn0, pn1;
+            v2f vc[TS], vn[TS];
+            asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(pc0) : "s"(prow) : "memory");
+            asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(pc1) : "s"(prow + (size_t)ast) : "memory");
 #pragma unroll
-            for (int h = 0; h < KVM; ++h)
-                asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(pc[h]) : "s"(prow + (size_t)h * ast) : "memory");
+            for (int u = 0; u < TS; ++u) vc[u] = (v2f){v0[u * hd], v0[u * hd + 64]};
 #pragma unroll
-            for (int u = 0; u < 8; ++u) vc[u] = (v2f){v0[u * hd], v0[u * hd + 64]};
-#pragma unroll
-            for (int tb = 0; tb < TCH; tb += 8) {
-                __builtin_amdgcn_s_waitcnt(kWaitLgkm0);            // this batch's probabilities (scalar) and V elements (LDS) have landed
+            for (int tb = 0; tb < TCH; tb += TS) {
+                __builtin_amdgcn_s_waitcnt(kWaitLgkm0);            // this stage's probabilities (scalar) and V elements (LDS) have landed
                 __builtin_amdgcn_sched_barrier(0);
-                if (tb + 8 < TCH) {
+                if (tb + TS < TCH) {
+                    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(pn0) : "s"(prow + tb + TS) : "memory");
+                    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(pn1) : "s"(prow + (size_t)ast + tb + TS) : "memory");
 #pragma unroll
-                    for (int h = 0; h < KVM; ++h)
-                        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(pn[h]) : "s"(prow + (size_t)h * ast + tb + 8) : "memory");
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) vn[u] = (v2f){v0[(tb + 8 + u) * hd], v0[(tb + 8 + u) * hd + 64]};
+                    for (int u = 0; u < TS; ++u) vn[u] = (v2f){v0[(tb + TS + u) * hd], v0[(tb + TS + u) * hd + 64]};
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-#pragma unroll
-                    for (int h = 0; h < KVM; ++h) {
-                        const float p = pc[h][u];
-                        o[h] = o[h] + vc[u] * (v2f){p, p};
-                    }
+                for (int u = 0; u < TS; ++u) {
+                    const float p0 = pc0[u], p1 = pc1[u];
+                    o0 = o0 + vc[u] * (v2f){p0, p0};
+                    o1 = o1 + vc[u] * (v2f){p1, p1};
                 }
-                if constexpr (KVM == 4) asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
-                else asm volatile("" : "+v"(o[0]), "+v"(o[1]));
-                if (tb + 8 < TCH) {
+                asm volatile("" : "+v"(o0), "+v"(o1));
+                if (tb + TS < TCH) {
+                    pc0 = pn0; pc1 = pn1;
 #pragma unroll
-                    for (int h = 0; h < KVM; ++h) pc[h] = pn[h];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) vc[u] = vn[u];
+                    for (int u = 0; u < TS; ++u) vc[u] = vn[u];
                 }
             }
             if (it == 8) GQA_STAMP(13);
@@ -1671,11 +1663,9 @@ __global__ __launch_bounds__(64 * NP, NP / 2) void k_attn_pf2(const AttnArgs a0)
     }
     GQA_STAMP(3);
     if (live) {
-#pragma unroll
-        for (int h = 0; h < KVM; ++h) {
-            const float oo[4] = {o[h].x, o[h].y, 0.0f, 0.0f};
-            gqa_store(a0, (size_t)pi, kvh * KVM + h, hd, lane, oo);
-        }
+        const float oa[4] = {o0.x, o0.y, 0.0f, 0.0f}, ob[4] = {o1.x, o1.y, 0.0f, 0.0f};
+        gqa_store(a0, (size_t)pi, head0, hd, lane, oa);
+        gqa_store(a0, (size_t)pi, head0 + 1, hd, lane, ob);
     }
     GQA_STAMP(4);
 }
