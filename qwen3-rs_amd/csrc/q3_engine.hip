@@ -212,6 +212,8 @@ struct q3_engine {
     // device-side Sampler (q3_sampler_set): temperature > 0 makes every token draw go through k_sample
     bool sampling = false;
     SamplerState* d_sampler = nullptr;
+    float* d_samp_hist = nullptr;        // pipelined draw: mass histogram, per-workgroup candidate counts
+    int* d_samp_counts = nullptr;
     float *d_probs = nullptr, *d_sp = nullptr;
     unsigned long long* d_keys = nullptr;
     size_t keys_n2 = 0;
@@ -396,7 +398,7 @@ void q3_engine::release() {
     if (graph_fwd) (void)hipGraphDestroy(graph_fwd);
     if (graph_fwd_long_exec) (void)hipGraphExecDestroy(graph_fwd_long_exec);
     if (graph_fwd_long) (void)hipGraphDestroy(graph_fwd_long);
-    void* dptrs[] = {d_next_cell, d_xbq, d_xbs, d_sampler, d_probs, d_sp, d_keys, d_prompt, d_att_priv, d_argmax_slots, d_stamps, d_blob, d_x, d_q, d_kraw, d_xb, d_hb, d_logits, d_tap, d_key, d_value, d_rope, d_att, d_state, d_out_tokens};
+    void* dptrs[] = {d_next_cell, d_xbq, d_xbs, d_samp_hist, d_samp_counts, d_sampler, d_probs, d_sp, d_keys, d_prompt, d_att_priv, d_argmax_slots, d_stamps, d_blob, d_x, d_q, d_kraw, d_xb, d_hb, d_logits, d_tap, d_key, d_value, d_rope, d_att, d_state, d_out_tokens};
     for (void* p : dptrs)
         if (p) (void)hipFree(p);
     if (h_logits) (void)hipHostFree(h_logits);
@@ -883,7 +885,19 @@ int q3_engine::enqueue_forward(bool eager, size_t pos, bool draw) {
 int q3_engine::enqueue_sample() {
     if (!sampling) return Q3_OK;
     if (sargs.pre_exp) hipLaunchKernelGGL(k_sample_exp, dim3((unsigned)n_cu, 1), dim3(256), 0, stream, sargs);
-    hipLaunchKernelGGL(k_sample, dim3(1), dim3(kSampThreads), 4 * kSegFloats, stream, sargs);
+    if (sargs.phase == 1) {
+        // pipelined draw: the single-workgroup kernel keeps the order-sensitive parts (exact sum; sort + exact walks), the
+        // element-wise passes over the vocabulary in between run on the whole chip
+        SampleArgs tail = sargs;
+        tail.phase = 2;
+        hipLaunchKernelGGL(k_sample, dim3(1), dim3(kSampThreads), 4 * kSegFloats, stream, sargs);
+        hipLaunchKernelGGL(k_sample_norm_hist, dim3(kSampGrid), dim3(256), 0, stream, sargs);
+        hipLaunchKernelGGL(k_sample_count, dim3(kSampGrid), dim3(256), 0, stream, sargs);
+        hipLaunchKernelGGL(k_sample_scatter, dim3(kSampGrid), dim3(256), 0, stream, sargs);
+        hipLaunchKernelGGL(k_sample, dim3(1), dim3(kSampThreads), 4 * kSegFloats, stream, tail);
+    } else {
+        hipLaunchKernelGGL(k_sample, dim3(1), dim3(kSampThreads), 4 * kSegFloats, stream, sargs);
+    }
     HIP_TRY(hipGetLastError());
     return Q3_OK;
 }
@@ -1050,6 +1064,12 @@ int q3_generate_greedy(q3_engine* e, size_t first_token, size_t first_pos, size_
         for (int f = 0; f < F_COUNT; ++f)
             if (cnt[f]) fprintf(stderr, "[q3 stamps] %-8s n=%d  issue %.0f  prologue %.0f  tile %.0f  finish %.0f  end %.0f  (s_memtime ticks after entry)\n", kFamilyNames[f], cnt[f], acc[f][1] / cnt[f], acc[f][2] / cnt[f], acc[f][3] / cnt[f], acc[f][4] / cnt[f], acc[f][5] / cnt[f]);
         for (int f = 0; f < F_COUNT; ++f) if (cnt[f] && acc[f][7] > 0 && f != F_ATTN) fprintf(stderr, "[q3 stamps] %-8s prologue detail: x/sum start %.0f  sum end %.0f  quantized %.0f\n", kFamilyNames[f], acc[f][6] / cnt[f], acc[f][7] / cnt[f], acc[f][8] / cnt[f]);
+        if (e->sampling) {
+            unsigned long long hs[16];
+            HIP_TRY(hipMemcpy(hs, e->d_stamps + 16 * (size_t)(5 * e->cfg.n_layers + 3), sizeof(hs), hipMemcpyDeviceToHost));
+            if (hs[0]) fprintf(stderr, "[q3 stamps] sample (last draw): sum %llu  normalise %llu  histogram %llu  compaction %llu  sort %llu  cumulative walk %llu  cdf walk %llu  total %llu ticks, %llu candidates\n",
+                               hs[1] - hs[0], hs[2] - hs[1], hs[3] - hs[2], hs[4] - hs[3], hs[5] - hs[4], hs[6] - hs[5], hs[7] - hs[6], hs[7] - hs[0], hs[9]);
+        }
         if (cnt[F_ATTN]) fprintf(stderr, "[q3 stamps] attn: issued %.0f  norm %.0f  staged %.0f  scores %.0f  softmax %.0f  vsum %.0f\n", acc[F_ATTN][1] / cnt[F_ATTN], acc[F_ATTN][2] / cnt[F_ATTN], acc[F_ATTN][3] / cnt[F_ATTN], acc[F_ATTN][4] / cnt[F_ATTN], acc[F_ATTN][5] / cnt[F_ATTN], acc[F_ATTN][6] / cnt[F_ATTN]);
     }
     if (getenv("Q3_DEBUG_TIMING"))
@@ -1100,9 +1120,12 @@ int q3_sampler_set(q3_engine* e, float temperature, float topp, uint64_t rng_see
         HIP_TRY(hipMalloc((void**)&e->d_probs, 4 * (size_t)kSampThreads * blen));
         HIP_TRY(hipMalloc((void**)&e->d_sp, 4 * (size_t)kSampThreads * blen));
         HIP_TRY(hipMalloc((void**)&e->d_keys, 2 * 8 * n2));
+        HIP_TRY(hipMalloc((void**)&e->d_samp_hist, 4 * kSampHistBins));
+        HIP_TRY(hipMalloc((void**)&e->d_samp_counts, 4 * kSampGrid));
         e->keys_n2 = n2;
     }
-    SamplerState h{rng_seed, temperature, topp, {0, 0, 0, 0}};
+    SamplerState h{};
+    h.rng = rng_seed; h.temperature = temperature; h.topp = topp;
     int rc = set_max_smem((const void*)k_sample, 4 * kSegFloats);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(e->d_sampler, &h, sizeof(h), hipMemcpyHostToDevice));
@@ -1119,6 +1142,10 @@ int q3_sampler_set(q3_engine* e, float temperature, float topp, uint64_t rng_see
     a.out_tokens = e->d_out_tokens;
     a.out_cap = e->out_cap;
     a.pre_exp = env_int("Q3_SAMPLER_PRE_EXP", 1);
+    a.phase = (a.pre_exp && env_int("Q3_SAMPLER_PIPELINE", 1)) ? 1 : 0;
+    a.hist = e->d_samp_hist;
+    a.counts = e->d_samp_counts;
+    a.stamps = e->d_stamps ? e->d_stamps + 16 * (size_t)(5 * e->cfg.n_layers + 3) : nullptr;
     e->sargs = a;
     e->sampling = temperature != 0.0f;                       // sampler.rs:119-120: temperature 0 is the argmax path
     return Q3_OK;

@@ -26,7 +26,15 @@ struct SamplerState {
     float temperature;
     float topp;
     int rounds[4];            // diagnostics: correction rounds of the last draw's exact prefix passes (softmax sum, cdf / nucleus)
+    // hand-over between the kernels of the pipelined draw (phase 1 -> chip-wide passes -> phase 2)
+    float inv;                // 1 / (exact softmax denominator)
+    float coin;               // this draw's uniform
+    int discard;              // a prompt-position draw: nothing to do
+    int n0;                   // candidates the chip-wide compaction wrote to keys[]
+    unsigned tkey0;           // probability-key threshold of the first attempt
 };
+constexpr int kSampGrid = 256;                         // workgroups of the chip-wide passes
+constexpr int kSampHistBins = 2048;
 
 struct SampleArgs {
     const float* logits;      // [n]
@@ -45,6 +53,12 @@ struct SampleArgs {
     // the engine's draws: e = exp(logit / T - max) was already written to probs[] by k_sample_exp (all CUs) -- the pass is
     // ~152k IEEE divisions + f64-pipe exps, ~0.2 ms when a single workgroup walks it
     int pre_exp;
+    unsigned long long* stamps;   // developer timeline (dev build, Q3_STAMPS=1)
+    // pipelined draw (single-stream engine): 0 = k_sample does everything; 1 = front (coin, exact sum -> SamplerState::inv);
+    // 2 = tail (sort, exact walks, result) behind k_sample_norm_hist / k_sample_count / k_sample_scatter
+    int phase;
+    float* hist;              // [kSampHistBins] probability mass per key bin (window below the maximum only)
+    int* counts;              // [kSampGrid] candidates per workgroup range
 };
 
 __device__ __forceinline__ float key_to_float(unsigned k) {
@@ -152,7 +166,7 @@ __device__ __forceinline__ int wg_first_crossing(const float* t, int blen, float
 // the `init` of the next.  visit(seg_base, in_j, out_j) runs after each segment's exact prefix (lane j: terms
 // [seg_base + 16 j, +16)) and returns true to stop early.  Returns the exact running sum after the last segment walked.
 constexpr int kSegBlen = 16;
-constexpr int kSegFloats = kSampThreads * kSegBlen;      // 64 KiB of LDS
+constexpr int kSegFloats = kSampThreads * kSegBlen;      // 64 KiB of LDS (8- and 32-term blocks measured: +25-30 us per draw)
 template <class Visit>
 __device__ __forceinline__ float wg_walk_segments(const float* t, int len, float init, float* seg, float* xch, float* carry_lds,
                                                   int* rounds_out, Visit&& visit) {
@@ -265,6 +279,11 @@ __device__ __forceinline__ unsigned long long* wg_radix_sort_desc(unsigned long 
     return src;
 }
 
+#ifdef Q3_DEV
+#define SAMP_STAMP(i) do { if (a_in.stamps != nullptr && threadIdx.x == 0) a_in.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SAMP_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a_in) {
     __shared__ float xch[kSampThreads + 16];
     __shared__ int red[4];
@@ -291,19 +310,23 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a_in) 
 
     // prompt positions of a chat-mode prefill: the reference draws (and discards) a sample per prompt token, which
     // advances the rng by exactly one coin; the input of the next forward stays the prompt token k_next selected
+    const int phase = a.phase;
     const bool discard = st->step < st->prompt_len;
+    float coin, inv;
+    const int n = a.n;
+    if (phase != 2) {
     __syncthreads();
     unsigned long long rs = ss->rng;
     rs ^= rs >> 12;
     rs ^= rs << 25;
     rs ^= rs >> 27;                                               // sampler.rs:44-49
     const unsigned r32 = (unsigned)((rs * 0x2545F4914F6CDD1Dull) >> 32);
-    const float coin = (float)(r32 >> 8) / 16777216.0f;          // sampler.rs:52-54
+    coin = (float)(r32 >> 8) / 16777216.0f;                      // sampler.rs:52-54
     __syncthreads();
     if (tid == 0) ss->rng = rs;
     if (discard) return;
 
-    const int n = a.n;
+    SAMP_STAMP(0);
     if (!a.pre_exp) {
         // ---- logits / temperature, max                                              sampler.rs:124-126, layers.rs:496
         float m = -__builtin_inff();
@@ -320,10 +343,24 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a_in) 
     __syncthreads();
     const float esum = wg_walk_segments(a.probs, n, -0.0f, seg, xch, &carry_lds, &ss->rounds[0],   // Iterator::sum from -0.0
                                         [](int, float, float) { return false; });
-    const float inv = 1.0f / esum;
+    inv = 1.0f / esum;
+    SAMP_STAMP(1);
+    if (phase == 1) {
+        // the chip-wide passes normalise, bin and compact; this workgroup clears their accumulators and hands over
+        for (int i = tid; i < kSampHistBins; i += kSampThreads) a.hist[i] = 0.0f;
+        if (tid == 0) { ss->inv = inv; ss->coin = coin; }
+        return;
+    }
     __syncthreads();
     for (int i = tid; i < n; i += kSampThreads) a.probs[i] = a.probs[i] * inv;
     __syncthreads();
+    SAMP_STAMP(2);
+    } else {
+        if (discard) return;
+        inv = ss->inv;
+        coin = ss->coin;
+        SAMP_STAMP(2);
+    }
 
     int result;
     if (topp <= 0.0f || topp >= 1.0f) {
@@ -349,6 +386,8 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a_in) 
         // largest probability (p_max = 1 * inv: the exp of the maximum is 1): the nucleus of a peaked distribution lives there,
         // the mass of the (many) tokens below the window is irrelevant, and their LDS atomics -- tens of thousands on a
         // handful of hot bins -- were the most expensive part of the draw.  A wave whose 64 values share a bin adds once.
+        unsigned tkey0 = 0u;
+        if (phase != 2) {
         for (int i = tid; i < 2048; i += kSampThreads) hmass[i] = 0.0f;
         __syncthreads();
         const unsigned bmax = total_order_key(inv) >> 21;
@@ -379,7 +418,9 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a_in) 
             ired[16] = (found && b > 0) ? b - 1 : 0;       // one bin of margin; nucleus below the window: every candidate
         }
         __syncthreads();
-        const unsigned tkey0 = (unsigned)ired[16] << 21;
+        tkey0 = (unsigned)ired[16] << 21;
+        }
+        SAMP_STAMP(3);
         int n0 = 0, hit = 0;
         const unsigned long long* sorted = a.keys;
         constexpr int NW = kSampThreads / 64;
@@ -388,6 +429,9 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a_in) 
         for (int attempt = 0; attempt < 2; ++attempt) {
             const unsigned tkey = attempt == 0 ? tkey0 : 0u;
             __syncthreads();
+            if (phase == 2 && attempt == 0) {
+                n0 = ss->n0;                                   // k_sample_scatter wrote the first attempt's candidates
+            } else {
             // candidates in index order: wave w owns the contiguous index range [w0, w1), 64 consecutive indices per load
             int cnt = 0;
             for (int base = w0; base < w1; base += 64) {
@@ -412,6 +456,11 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a_in) 
                 if (c) a.keys[run + rank] = ((unsigned long long)total_order_key(p) << 32) | (unsigned)(0xffffffffu - (unsigned)i);
                 run += __builtin_popcountll(mask);
             }
+            }
+            if (attempt == 0) SAMP_STAMP(4);
+#ifdef Q3_DEV
+            if (a_in.stamps != nullptr && tid == 0 && attempt == 0) a_in.stamps[9] = (unsigned long long)n0;
+#endif
             int n2 = 1;
             while (n2 < n0) n2 <<= 1;
             const unsigned long long* ks = a.keys;            // sorted candidates
@@ -438,6 +487,7 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a_in) 
                 }
             }
             sorted = ks;
+            if (attempt == 0) SAMP_STAMP(5);
             for (int i = tid; i < n0; i += kSampThreads) a.sp[i] = key_to_float((unsigned)(ks[i] >> 32));
             __syncthreads();
             // cumulative probability in sorted order, truncation point, then the cdf walk with r = coin * cumulative
@@ -450,6 +500,7 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a_in) 
                 if (h >= 0) { last_idx = base + h; cumulative = cum; }
                 return h >= 0;
             });
+            if (attempt == 0) SAMP_STAMP(6);
             const bool crossed = last_idx >= 0 && last_idx < n0;
             if (!crossed && attempt == 0) continue;                                             // prefix too short: sort everything
             if (!crossed) { last_idx = n0 - 1; cumulative = total; }
@@ -466,6 +517,10 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a_in) 
         }
         result = (n0 > 0) ? (int)(0xffffffffu - (unsigned)(sorted[hit] & 0xffffffffull)) : 0;
     }
+    SAMP_STAMP(7);
+#ifdef Q3_DEV
+    if (a_in.stamps != nullptr && tid == 0) a_in.stamps[8] = (unsigned long long)(topp > 0.0f && topp < 1.0f ? 1 : 0);
+#endif
     if (tid == 0) {
         // k_next already advanced (pos, step) and stored the argmax: the sampled token replaces it
         st->token = result;
@@ -488,6 +543,141 @@ __global__ __launch_bounds__(256) void k_sample_exp(const SampleArgs a_in) {
     float* probs = a_in.probs + sb * a_in.sb_scratch;
     const float m = key_to_float((unsigned)(st->argmax >> 32)) / temperature;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < a_in.n; i += gridDim.x * 256) probs[i] = q3_expf(logits[i] / temperature - m);
+}
+
+// ---- chip-wide passes of the pipelined draw (grid kSampGrid, one stream).  None of them touches an order-sensitive quantity:
+// p = e * inv is element-wise, the mass histogram only chooses a threshold (any threshold gives the same draw: the tail kernel
+// verifies that the sorted prefix crosses topp and otherwise repeats with every candidate), and the compaction writes the
+// candidates in ascending index order exactly as the single-workgroup pass does.
+__device__ __forceinline__ bool samp_skip(const SampleArgs& a) {
+    const State* st = a.st;
+    const SamplerState* ss = a.ss;
+    return st->step < st->prompt_len || !(ss->topp > 0.0f && ss->topp < 1.0f);
+}
+// thread 0's scan of the window bins (same rule as k_sample), broadcast through LDS
+__device__ __forceinline__ unsigned samp_threshold(const SampleArgs& a, float inv, float topp, unsigned* lds_word) {
+    if (threadIdx.x == 0) {
+        const unsigned bmax = total_order_key(inv) >> 21;
+        const unsigned bfloor = bmax > 64u ? bmax - 64u : 0u;
+        float acc = 0.0f;
+        int b = kSampHistBins - 1;
+        bool found = false;
+        for (b = (int)min(bmax, (unsigned)kSampHistBins - 1u); b > (int)bfloor; --b) {
+            acc += a.hist[b];
+            if (acc > topp * 1.001f + 1e-6f) { found = true; break; }
+        }
+        *lds_word = ((found && b > 0) ? (unsigned)(b - 1) : 0u) << 21;
+    }
+    __syncthreads();
+    return *lds_word;
+}
+__global__ __launch_bounds__(256) void k_sample_norm_hist(const SampleArgs a) {
+    __shared__ float hm[66];
+    const State* st = a.st;
+    const SamplerState* ss = a.ss;
+    if (st->step < st->prompt_len) return;
+    const float inv = ss->inv, topp = ss->topp;
+    const bool nucleus = topp > 0.0f && topp < 1.0f;
+    const int n = a.n, tid = threadIdx.x, lane = tid & 63;
+    const float cutoff = (1.0f - topp) / (float)((n - 1) > 1 ? (n - 1) : 1);
+    const unsigned bmax = total_order_key(inv) >> 21;
+    const unsigned bfloor = bmax > 64u ? bmax - 64u : 0u;
+    if (tid < 66) hm[tid] = 0.0f;
+    __syncthreads();
+    for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
+        const int i = i0 + tid;
+        float p = 0.0f;
+        if (i < n) { p = a.probs[i] * inv; a.probs[i] = p; }                 // layers.rs:503-505
+        if (!nucleus) continue;
+        const unsigned bin = total_order_key(p) >> 21;
+        const bool in = i < n && p >= cutoff && bin >= bfloor && bin <= bmax;
+        const unsigned tag = in ? bin : 0xffffffffu;
+        const unsigned first = (unsigned)__builtin_amdgcn_readfirstlane((int)tag);
+        if (__all(tag == first)) {
+            if (first != 0xffffffffu) {
+                const float sw = group_sum_f32(p, 64);
+                if (lane == 0) atomicAdd(&hm[first - bfloor], sw);
+            }
+        } else if (in) atomicAdd(&hm[bin - bfloor], p);
+    }
+    __syncthreads();
+    if (nucleus && tid < 66 && hm[tid] != 0.0f && bfloor + tid < (unsigned)kSampHistBins) atomicAdd(&a.hist[bfloor + tid], hm[tid]);
+}
+// workgroup g owns the contiguous index range [g * per, (g + 1) * per): counts its candidates
+__global__ __launch_bounds__(256) void k_sample_count(const SampleArgs a) {
+    __shared__ unsigned tk;
+    __shared__ int wsum[4];
+    if (samp_skip(a)) return;
+    SamplerState* ss = a.ss;
+    const float topp = ss->topp;
+    const int n = a.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float cutoff = (1.0f - topp) / (float)((n - 1) > 1 ? (n - 1) : 1);
+    const unsigned tkey = samp_threshold(a, ss->inv, topp, &tk);
+    const int per = ((n + (int)gridDim.x * 256 - 1) / ((int)gridDim.x * 256)) * 256;
+    const int g0 = min((int)blockIdx.x * per, n), g1 = min(g0 + per, n);
+    int cnt = 0;
+    for (int i = g0 + tid; i < g1; i += 256) {
+        const float p = a.probs[i];
+        cnt += (p >= cutoff && total_order_key(p) >= tkey) ? 1 : 0;
+    }
+    cnt = (int)group_sum_f32((float)cnt, 64);                                   // <= 64 * per / 256: exact in f32
+    if (lane == 0) wsum[wave] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        a.counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (blockIdx.x == 0) ss->tkey0 = tkey;
+    }
+}
+// ... and writes them to keys[] in ascending index order behind the candidates of the lower ranges
+__global__ __launch_bounds__(256) void k_sample_scatter(const SampleArgs a) {
+    __shared__ int wcnt[4];
+    __shared__ int base_s;
+    if (samp_skip(a)) return;
+    SamplerState* ss = a.ss;
+    const float topp = ss->topp;
+    const int n = a.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float cutoff = (1.0f - topp) / (float)((n - 1) > 1 ? (n - 1) : 1);
+    const unsigned tkey = ss->tkey0;
+    const int per = ((n + (int)gridDim.x * 256 - 1) / ((int)gridDim.x * 256)) * 256;
+    const int g0 = min((int)blockIdx.x * per, n), g1 = min(g0 + per, n);
+    // candidates of the lower workgroup ranges (and, on workgroup 0, of all ranges: n0)
+    {
+        int lo = 0, all = 0;
+        for (int w = tid; w < (int)gridDim.x; w += 256) { const int c = a.counts[w]; all += c; lo += w < (int)blockIdx.x ? c : 0; }
+        lo = (int)group_sum_f32((float)lo, 64);                                  // < 2^24 candidates: exact in f32
+        all = (int)group_sum_f32((float)all, 64);
+        if (lane == 0) { wcnt[wave] = lo; }
+        __syncthreads();
+        if (tid == 0) base_s = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+        if (lane == 0) wcnt[wave] = all;
+        __syncthreads();
+        if (tid == 0 && blockIdx.x == 0) ss->n0 = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+    }
+    // wave w owns a contiguous quarter of the range
+    const int perw = per / 4;
+    const int w0 = min(g0 + wave * perw, g1), w1 = min(w0 + perw, g1);
+    int cnt = 0;
+    for (int b = w0; b < w1; b += 64) {
+        const int i = b + lane;
+        const float p = i < w1 ? a.probs[i] : 0.0f;
+        const bool c = i < w1 && p >= cutoff && total_order_key(p) >= tkey;
+        cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(c));
+    }
+    if (lane == 0) wcnt[wave] = cnt;
+    __syncthreads();
+    int run = base_s;
+    for (int w = 0; w < wave; ++w) run += wcnt[w];
+    for (int b = w0; b < w1; b += 64) {
+        const int i = b + lane;
+        const float p = i < w1 ? a.probs[i] : 0.0f;
+        const bool c = i < w1 && p >= cutoff && total_order_key(p) >= tkey;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(c);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        if (c) a.keys[run + rank] = ((unsigned long long)total_order_key(p) << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+        run += __builtin_popcountll(mask);
+    }
 }
 
 // advance the xorshift64* stream by `count` coins (batched prefill: one discarded sample per prompt position)
