@@ -1164,24 +1164,8 @@ __global__ __launch_bounds__(kG2Threads) void k_attn_gqa2(const AttnArgs a0) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Prefill attention (round 3; head_dim 128, KVM = 2 or 4 query heads per kv head): one 4-wave workgroup per (kv head, FOUR
-// consecutive positions of the block).  Wave w owns position 4*blockIdx.y + w and runs the KVM query heads of the kv head
-// as interleaved chains, so
-//   * every K / V chunk (64 timesteps) is staged in LDS once for 4 positions x KVM heads -- k_attn_gqa2 stages it once per
-//     position, and at a context of 2,048 its launches moved ~0.5 GB each through L2 (12 TB/s: the staging, not the
-//     arithmetic, set their 44 us);
-//   * a lane keeps its K row in registers for all KVM dots and walks two dot chains at a time: the 10-cycle dependent add
-//     of one chain no longer leaves the SIMD idle (one chain per wave used ~40 % of the issue slots);
-//   * the V pass walks 2*KVM chains per lane (elements lane, lane+64 of every head), the probabilities arrive as scalars
-//     (v_readlane of this lane-per-timestep register), V rows are read once per timestep for all heads.
-// Arithmetic and order per (head, position) are those of k_attn_gqa2 / k_attn / the reference (layers.rs:346-419,495-506):
-// bit-identical results.  Score rows live in a global scratch row per (position, head) (they do not fit LDS for 4 x KVM
-// rows); the key rows of the whole block are already in the cache (k_knorm_rope).
+// Dense-prefill attention helpers (k_attn_pf2 below)
 // ------------------------------------------------------------------------------------------------
-// NP = positions (= waves) per workgroup: 4 (256 threads) or 8 (512 threads: two waves per SIMD, half the staging traffic)
-__host__ __device__ inline size_t attn_pf_smem_bytes(int kvm, int npw) {
-    return 4 * (2 * (size_t)kG2Tch * (kG2Hd + kKPad) + (size_t)npw * kvm * kG2Hd * 2 + (size_t)npw * kG2Hd) + 32 * 8;
-}
 // exact sequential sum (from -0.0) of row[0 .. np): NQ float4 per lane, blocks of 4*NQ consecutive terms, terms past np are +0.0
 template <int NQ>
 __device__ __forceinline__ float row_exact_sum_regs(const float* row, int np) {
@@ -1223,214 +1207,15 @@ __device__ __forceinline__ float row_exact_sum(const float* row, int np) {
     });
 }
 
-template <int KVM, int NP>
-__global__ __launch_bounds__(64 * NP) void k_attn_pf(const AttnArgs a0) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int hd = kG2Hd, kld = hd + kKPad, TCH = kG2Tch, TILE = TCH * kld, NQ4 = hd / 4;
-    constexpr int kPfPos = NP, NTHR = 64 * NP, NSL = TCH * (hd / 4) / NTHR;        // staging float4 per thread: 8 / 4
-    float* tiles = (float*)smem_raw;                               // 2 x [TCH][kld]   (V: [TCH][hd])
-    float* q_s = tiles + 2 * TILE;                                 // [kPfPos][KVM][hd] normalised + rotated queries
-    float* sq = q_s + kPfPos * KVM * hd;                           // [kPfPos][KVM][hd] scratch of the norm (raw | squares)
-    float* rawb = sq + kPfPos * KVM * hd;                          // [kPfPos][hd]
-    unsigned long long* etab = (unsigned long long*)(rawb + kPfPos * hd);
-    const int kvh = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pi0 = blockIdx.y * kPfPos;
-    const int n_pos = a0.n_pos;                                    // positions in the block (>= 1); their key rows are in the cache
-    const int pi = min(pi0 + wave, n_pos - 1);
-    const bool live = pi0 + wave < n_pos;                          // wave-uniform
-    const size_t kvd = (size_t)a0.n_kv_heads * hd;
-    const int ast = a0.att_stride;
-    const int pos = __builtin_amdgcn_readfirstlane(a0.st[pi].pos);
-    const int pos_last = __builtin_amdgcn_readfirstlane(a0.st[min(pi0 + kPfPos - 1, n_pos - 1)].pos);
-    const int np = pos + 1, np_max = pos_last + 1;                 // positions of a block are consecutive and ascending
-    const float* kbase = a0.key_cache + (size_t)kvh * hd;
-    const float* vbase = a0.value_cache + (size_t)kvh * hd;
-    if (tid < 32) etab[tid] = kExp2Tab[tid];
-
-    // ---- K chunk staging: 64 rows x 32 float4 = NSL float4 per thread
-    v4f sr[NSL];
-    auto issue = [&](const float* gbase, int t0) {
-#pragma unroll
-        for (int u = 0; u < NSL; ++u) {
-            const int idx = tid + u * NTHR;
-            const int row = min(t0 + (idx >> 5), np_max - 1), c = idx & 31;
-            sr[u] = *(const v4f*)(gbase + (size_t)row * kvd + 4 * c);
-        }
-    };
-    auto commit = [&](float* tile, int ld) {
-#pragma unroll
-        for (int u = 0; u < NSL; ++u) {
-            const int idx = tid + u * NTHR;
-            *(v4f*)(tile + (idx >> 5) * ld + 4 * (idx & 31)) = sr[u];
-        }
-    };
-    issue(kbase, 0);
-
-    // ---- QK-RMSNorm + RoPE of this position's KVM query heads (layers.rs:346-360), one head after the other
-    {
-        const float* cs = a0.rope + (size_t)pos * hd;
-        RopeRegs rr;
-        rope_regs_load(rr, a0.q_norm_w, cs, hd);
-        float* raw_w = rawb + wave * hd;
-#pragma unroll
-        for (int h = 0; h < KVM; ++h) {
-            const float* qsrc = a0.q + (size_t)pi * a0.sb_q + (size_t)(kvh * KVM + h) * hd;
-            raw_w[lane] = qsrc[lane];
-            raw_w[lane + 64] = qsrc[lane + 64];
-            wave_lds_sync();
-            wave_norm_rope(q_s + (wave * KVM + h) * hd, raw_w, sq + (wave * KVM + h) * hd, rr, hd, 1);
-            wave_lds_sync();
-        }
-    }
-    const float scale = 1.0f / sqrtf((float)hd);                   // (head_dim as f32).sqrt().recip()
-    float* rows = a0.att_global + ((size_t)pi * a0.n_heads + (size_t)kvh * KVM) * ast;      // score row of (position, head): (pi*n_heads + head) * ast
-
-    // ---- scores: att[h][t] = (q_h . K[t]) * scale, one timestep per lane, two heads' chains at a time      layers.rs:391-401
-    for (int c0 = 0, it = 0; c0 < np_max; c0 += TCH, ++it) {
-        float* tile = tiles + (it & 1) * TILE;
-        commit(tile, kld);
-        __syncthreads();
-        if (c0 + TCH < np_max) issue(kbase, c0 + TCH);
-        if (live && c0 < np) {
-            const int t = c0 + lane;
-            v4f kr[NQ4];
-            const v4f* k4 = (const v4f*)(tile + lane * kld);
-#pragma unroll
-            for (int i = 0; i < NQ4; ++i) kr[i] = k4[i];
-#pragma unroll
-            for (int hp = 0; hp < KVM; hp += 2) {
-                const v4f* qa4 = (const v4f*)(q_s + (wave * KVM + hp) * hd);
-                const v4f* qb4 = qa4 + NQ4;
-                float d0 = -0.0f, d1 = -0.0f;
-                constexpr int QB = 4;                              // float4 of q per head and batch (the next batch is in flight)
-                v4f xa[QB], xb[QB], ya[QB], yb[QB];
-#pragma unroll
-                for (int u = 0; u < QB; ++u) { xa[u] = qa4[u]; xb[u] = qb4[u]; }
-#pragma unroll
-                for (int b = 0; b < NQ4 / QB; ++b) {
-                    if (b + 1 < NQ4 / QB) {
-#pragma unroll
-                        for (int u = 0; u < QB; ++u) { ya[u] = qa4[QB * (b + 1) + u]; yb[u] = qb4[QB * (b + 1) + u]; }
-                    }
-#pragma unroll
-                    for (int u = 0; u < QB; ++u) {
-                        const v4f kk = kr[QB * b + u];
-                        const v4f p0 = xa[u] * kk, p1 = xb[u] * kk;        // products are independent of the chains
-                        d0 = d0 + p0.x; d1 = d1 + p1.x;
-                        d0 = d0 + p0.y; d1 = d1 + p1.y;
-                        d0 = d0 + p0.z; d1 = d1 + p1.z;
-                        d0 = d0 + p0.w; d1 = d1 + p1.w;
-                    }
-#pragma unroll
-                    for (int u = 0; u < QB; ++u) { xa[u] = ya[u]; xb[u] = yb[u]; }
-                }
-                if (t < np) {
-                    rows[(size_t)hp * ast + t] = d0 * scale;
-                    rows[(size_t)(hp + 1) * ast + t] = d1 * scale;
-                }
-            }
-        }
-    }
-    __syncthreads();                                               // every wave is done with the K tiles
-    issue(vbase, 0);                                               // V chunk 0 travels under the softmax
-
-    // ---- softmax per (position, head) row (layers.rs:495-506): max, exp in place, exact sequential sum; p = e * inv is
-    // formed in the V pass (same two roundings as normalising the row first)
-    float inv[KVM];
-#pragma unroll
-    for (int h = 0; h < KVM; ++h) inv[h] = 0.0f;
-    if (live) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's score stores have landed (it reads them back)
-#pragma unroll
-        for (int h = 0; h < KVM; ++h) {
-            float* row = rows + (size_t)h * ast;
-            float m = -__builtin_inff();
-            for (int t = lane; t < np; t += 64) m = fmaxf(m, row[t]);
-            m = group_max_f32(m, 64);
-            for (int t0 = 0; t0 < np; t0 += 256) {                  // four exps per lane at a time (their f64 chains interleave)
-                float ev[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int t = t0 + 64 * u + lane;
-                    const float x = row[min(t, np - 1)];
-                    ev[u] = q3_expf_t(x - m, etab);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int t = t0 + 64 * u + lane;
-                    if (t < np) row[t] = ev[u];
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const float sum = row_exact_sum(row, np);
-            inv[h] = 1.0f / sum;
-        }
-    }
-
-    // ---- xb = sum_t att[t] * V[t]  (fill(0.0) then += in t order): 2 * KVM chains per lane              layers.rs:406-417
-    float o0[KVM], o1[KVM];
-#pragma unroll
-    for (int h = 0; h < KVM; ++h) { o0[h] = 0.0f; o1[h] = 0.0f; }
-    for (int c0 = 0, it = 0; c0 < np_max; c0 += TCH, ++it) {
-        float* tile = tiles + (it & 1) * TILE;
-        commit(tile, hd);
-        __syncthreads();
-        if (c0 + TCH < np_max) issue(vbase, c0 + TCH);
-        if (live && c0 < np) {
-            float pe[KVM];
-#pragma unroll
-            for (int h = 0; h < KVM; ++h) {
-                const int t = c0 + lane;
-                const float e = rows[(size_t)h * ast + min(t, np - 1)];
-                pe[h] = (t < np) ? e * inv[h] : 0.0f;              // layers.rs:503-505; +0.0 past the context
-            }
-            const int cnt = min(TCH, np - c0);
-            const float* v0 = tile + lane;
-            auto step = [&](int tt) {
-                const float va = v0[tt * hd], vb = v0[tt * hd + 64];
-#pragma unroll
-                for (int h = 0; h < KVM; ++h) {
-                    const float p = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pe[h]), tt));
-                    const float x0 = p * va, x1 = p * vb;
-                    o0[h] = o0[h] + x0;
-                    o1[h] = o1[h] + x1;
-                }
-            };
-            if (cnt == TCH) {
-#pragma unroll 16
-                for (int tt = 0; tt < TCH; ++tt) step(tt);
-            } else {
-                // the context's last chunk: timesteps past it would add p = +0.0 times a finite V row (o + 0.0 == o, o is never
-                // -0.0), but the V tile rows past np_max were clamped re-reads -- still finite; walk only the live ones
-#pragma unroll 1
-                for (int tb = 0; tb < TCH; tb += 8) {
-                    if (tb < cnt) {
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) if (tb + u < cnt) step(tb + u);
-                    }
-                }
-            }
-        }
-    }
-    if (live) {
-#pragma unroll
-        for (int h = 0; h < KVM; ++h) {
-            const float o[4] = {o0[h], o1[h], 0.0f, 0.0f};
-            gqa_store(a0, (size_t)pi, kvh * KVM + h, hd, lane, o);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// k_attn_pf2: k_attn_pf with the wave-uniform operands in SCALAR registers and one wave per (position, head PAIR).
+// k_attn_pf2 (round 3; head_dim 128, KVM = 2 or 4 query heads per kv head): dense-prefill attention with the wave-uniform
+// operands in SCALAR registers and one wave per (position, head PAIR).  (Its first form, k_attn_pf -- q read from LDS, one wave
+// per position, the K row held in 128 registers -- ran 240 us per (layer, block) where this one runs 126; removed.)
 // One workgroup per kv head x NP consecutive positions; the K / V chunks (64 timesteps) are staged in LDS once for its
 // NP x KVM query rows; wave w owns position w / (KVM/2) and the two query heads of pair w % (KVM/2) -- 16 waves for
 // Qwen3-4B/8B (four per SIMD: the latency of one wave's scalar loads, barriers and softmax passes is another wave's
 // issue slot; with one wave per position the kernel ran two per SIMD and waited half of the time).  Arithmetic and order per
-// (head, position) are those of k_attn_pf / k_attn / the reference (layers.rs:346-419,495-506): bit-identical results.
+// (head, position) are those of k_attn_gqa2 / k_attn / the reference (layers.rs:346-419,495-506): bit-identical results.
 //   * q is normalised + rotated by k_knorm_rope (one launch for the block's K and q heads) and stored pair-interleaved; the
 //     score loop reads it with s_load (constant address space) and forms the two heads' products with one v_pk_mul_f32
 //     (K element broadcast by op_sel) and extends the two chains with one v_pk_add_f32: 2 VALU per dim and pair, no LDS

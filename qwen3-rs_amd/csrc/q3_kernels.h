@@ -1436,7 +1436,7 @@ struct AttnArgs {
     int8_t* xbq;
     float* xbs;
     int xb_group;
-    int n_pos;                // k_attn_pf (dense prefill): positions in the block
+    int n_pos;                // k_attn_pf2 (dense prefill): positions in the block
 };
 
 // LDS plan of k_attn (floats): q_s[hd] k_s[hd] raw[2hd] sq[2hd] opart[kWaves*hd] red[64] att[att_lds]
