@@ -161,6 +161,10 @@ int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
 }
+// activation requests ahead of the weight requests (GemvArgs::xfirst): 2 = workgroup barrier between them (default for the
+// 16-wave workgroups: r03 A/B), 1 = wait for wave 0's block of x, 0 = program order only
+int xfirst_dflt(int wgt) { return wgt >= 1024 ? env_int("Q3_XFIRST_DEFAULT", 2) : 0; }
+
 
 }  // namespace
 
@@ -626,7 +630,7 @@ int q3_engine::build_plan() {
                 a.x_out = d_x;
             }
             if (cfg) {
-                a.xfirst = env_int("Q3_XFIRST", dim >= 2048 ? 1 : 0);
+                a.xfirst = env_int("Q3_XFIRST", xfirst_dflt(cfg->wgt));
                 apply_cfg(Ln, a, *cfg, a.total_rows, n_cu);
             } else {
                 const GemvShape gs = plan_gemv(a.total_rows, dim, G, false, hd, n_cu, small_cap);
@@ -726,6 +730,7 @@ int q3_engine::build_plan() {
             a.norm_w = rms_ffn + (size_t)l * dim;
             a.in = d_x;
             if (const GemvCfg* cfg = find_cfg(PRO_NORM, EPI_SWIGLU, dim, G, env_int("Q3_CFG_W13", 0))) {
+                a.xfirst = env_int("Q3_XFIRST_W13", dim < 2048 ? xfirst_dflt(cfg->wgt) : 0);   // 8B: -0.4 %, 4B: neutral, 0.6B: +5 %
                 apply_cfg(Ln, a, *cfg, H, n_cu);
             } else {
                 const GemvShape gs = plan_gemv(H, dim, G, true, 1, n_cu, small_cap);
@@ -748,6 +753,7 @@ int q3_engine::build_plan() {
             a.total_rows = dim;
             a.in = d_hb;
             if (const GemvCfg* cfg = find_cfg(PRO_QUANT, EPI_RESID, H, G, env_int("Q3_CFG_W2", 0))) {
+                a.xfirst = env_int("Q3_XFIRST_W2", 0);                                           // 8B: -0.4 %, 4B: +0.3 %
                 apply_cfg(Ln, a, *cfg, dim, n_cu);
             } else {
                 const GemvShape gs = plan_gemv(dim, H, G, false, 1, n_cu, small_cap);
@@ -775,6 +781,7 @@ int q3_engine::build_plan() {
         GemvShape gs = plan_gemv(V, dim, G, false, 1, n_cu, big_cap, false);
         const GemvCfg* lcfg = find_cfg(PRO_NORM, EPI_LOGITS, dim, G, env_int("Q3_CFG_LMHEAD", 1));
         if (lcfg) {
+            a.xfirst = env_int("Q3_XFIRST_LM", 0);
             apply_cfg(Ln, a, *lcfg, V, n_cu);
             // streaming launch: cap the grid at the resident set (grid-stride over the row batches)
             const unsigned cap = (unsigned)(n_cu * (lcfg->wgt >= 512 ? 1 : 2));

@@ -1042,7 +1042,7 @@ __global__ __launch_bounds__(WGT) void k_gemv(const GemvArgs a) {
         }
     } else if constexpr (kPro2) {
         if constexpr (PRO == PRO_NORM || PRO == PRO_EMBED_NORM) {
-            if (a.xfirst) {                   // wave-uniform: wave 0's block of x travels alone, everything else behind it
+            if (a.xfirst) {                   // wave-uniform (A/B knob, off by default): wave 0's block of x travels alone, everything else behind it
                 pro2_issue<PRO, N_T, WGT, EPT>(a, pr2, 1);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
@@ -1050,6 +1050,14 @@ __global__ __launch_bounds__(WGT) void k_gemv(const GemvArgs a) {
                 pro2_issue<PRO, N_T, WGT, EPT>(a, pr2, 2);
             } else pro2_issue<PRO, N_T, WGT, EPT>(a, pr2, 0);
         } else pro2_issue<PRO, N_T, WGT, EPT>(a, pr2, 0);
+        if (a.xfirst == 2) {
+            // every wave's activation requests enter the CU's address path before any weight request does: a dwordx4 load of a
+            // wave occupies that path for 16 cycles, and wave 0's 17 block loads otherwise interleave with the other 15 waves'
+            // 16 tile loads each -- its block (the exact sum's input) finished ISSUING ~3,000 cycles after entry (r03 stamps)
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+        }
     } else gemv_prologue_issue<PRO>(a, pr);
     // EPI_QKV: the position is REQUESTED here (behind the activation, ahead of the weights) and only turned into a scalar
     // after the prologue -- a v_readfirstlane right here made hipcc wait for every load above before the first weight tile
