@@ -386,7 +386,7 @@ void apply_cfg(Launch& Ln, GemvArgs& a, const GemvCfg& c, int units, int n_cu) {
     Ln.grid = (unsigned)grid;
     Ln.block = (unsigned)c.wgt;
     // f32 staging only for the long vectors' block transpose (wave 0 sums out of registers)
-    const bool stage = (c.pro == PRO_NORM || c.pro == PRO_EMBED_NORM) && c.n > 1024;
+    const bool stage = (c.pro == PRO_NORM || c.pro == PRO_EMBED_NORM) && c.n >= 1024;
     Ln.smem = gemv_smem_bytes(c.n, 64, c.ru, stage, waves, true);
 }
 

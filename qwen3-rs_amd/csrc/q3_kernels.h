@@ -753,7 +753,7 @@ struct Pro2 {
     // (r03 first cut: every wave of a 16-wave workgroup ran the sum redundantly; four waves per SIMD interleaving the same
     // ~300-instruction loop made it issue-bound and the prologue no faster than with 4-wave workgroups.)
     static constexpr int NQ = kNorm ? N / 256 : 1;        // float4 per lane of wave 0
-    static constexpr bool kBlkViaLds = (PRO == PRO_NORM) && NQ > 4;   // coalesced loads + LDS transpose (see pro2_issue)
+    static constexpr bool kBlkViaLds = (PRO == PRO_NORM) && NQ >= 4;   // coalesced loads + LDS transpose (see pro2_issue)
     float x[NP][EPT];
     float w[NP][EPT];
     v4f blk[NQ];
@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(WGT) void k_gemv(const GemvArgs a) {
     constexpr int HU = (EPI == EPI_SWIGLU) ? (RU / 2) : RU;   // rows per run
     static_assert(EPI != EPI_SWIGLU || RU >= 2, "SwiGLU tiles hold a w1 and a w3 row");
     const int n = kSpec ? N_T : a.n, G = kSpec ? 64 : a.group;
-    const GemvSmem sm = gemv_carve(smem_raw, n, G, RU, kStage && (!kSpec || n > 1024), WAVES, FIN != 0);
+    const GemvSmem sm = gemv_carve(smem_raw, n, G, RU, kStage && (!kSpec || n >= 1024), WAVES, FIN != 0);
 
     const int lpg_shift = (LPG_T > 0) ? __builtin_ctz(LPG_T) : __builtin_ctz(G >> 4);   // G is a power of two >= 16
     const int lpg = 1 << lpg_shift;
