@@ -161,8 +161,10 @@ int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
 }
-// activation requests ahead of the weight requests (GemvArgs::xfirst): 2 = workgroup barrier between them (default for the
-// 16-wave workgroups: r03 A/B), 1 = wait for wave 0's block of x, 0 = program order only
+// activation requests ahead of the weight requests (GemvArgs::xfirst): 2 = workgroup barrier between them, 1 = wait for wave 0's
+// block of x, 0 = program order only.  r03 A/B in reference-order mode (tools/gen_loop.py, Q3_STRICT=1): the barrier costs the QKV
+// launch 0.15 us at every shape (0.6B: 1,572 -> 1,527 tok/s), gains W13 0.4 us at dim 1024 (+0.3 %) and nothing at 2560 / 4096;
+// in Q3_FLAG_FAST mode (no exact sum in front of the quantizer) it is worth +6 % on the 0.6B shape.
 int xfirst_dflt(int wgt) { return wgt >= 1024 ? env_int("Q3_XFIRST_DEFAULT", 2) : 0; }
 
 
@@ -630,7 +632,7 @@ int q3_engine::build_plan() {
                 a.x_out = d_x;
             }
             if (cfg) {
-                a.xfirst = env_int("Q3_XFIRST", xfirst_dflt(cfg->wgt));
+                a.xfirst = env_int("Q3_XFIRST", (flags & Q3_FLAG_FAST) ? xfirst_dflt(cfg->wgt) : 0);
                 apply_cfg(Ln, a, *cfg, a.total_rows, n_cu);
             } else {
                 const GemvShape gs = plan_gemv(a.total_rows, dim, G, false, hd, n_cu, small_cap);
@@ -730,7 +732,7 @@ int q3_engine::build_plan() {
             a.norm_w = rms_ffn + (size_t)l * dim;
             a.in = d_x;
             if (const GemvCfg* cfg = find_cfg(PRO_NORM, EPI_SWIGLU, dim, G, env_int("Q3_CFG_W13", 0))) {
-                a.xfirst = env_int("Q3_XFIRST_W13", dim < 2048 ? xfirst_dflt(cfg->wgt) : 0);   // 8B: -0.4 %, 4B: neutral, 0.6B: +5 %
+                a.xfirst = env_int("Q3_XFIRST_W13", dim < 2048 ? xfirst_dflt(cfg->wgt) : 0);
                 apply_cfg(Ln, a, *cfg, H, n_cu);
             } else {
                 const GemvShape gs = plan_gemv(H, dim, G, true, 1, n_cu, small_cap);
@@ -753,7 +755,7 @@ int q3_engine::build_plan() {
             a.total_rows = dim;
             a.in = d_hb;
             if (const GemvCfg* cfg = find_cfg(PRO_QUANT, EPI_RESID, H, G, env_int("Q3_CFG_W2", 0))) {
-                a.xfirst = env_int("Q3_XFIRST_W2", 0);                                           // 8B: -0.4 %, 4B: +0.3 %
+                a.xfirst = env_int("Q3_XFIRST_W2", 0);
                 apply_cfg(Ln, a, *cfg, dim, n_cu);
             } else {
                 const GemvShape gs = plan_gemv(dim, H, G, false, 1, n_cu, small_cap);

@@ -740,6 +740,9 @@ template <int LANES> __device__ __forceinline__ float group_max_c(float v) {
     if constexpr (LANES <= 16) return group_max_f32_t<LANES>(v);
     else return group_max_f32(v, LANES);
 }
+#ifndef Q3_BLK_LDS_MIN
+#define Q3_BLK_LDS_MIN 4
+#endif
 template <int PRO, int N, int WGT, int EPT>
 struct Pro2 {
     static constexpr int EPP = EPT * WGT;                 // elements per pass of the whole workgroup
@@ -753,7 +756,7 @@ struct Pro2 {
     // (r03 first cut: every wave of a 16-wave workgroup ran the sum redundantly; four waves per SIMD interleaving the same
     // ~300-instruction loop made it issue-bound and the prologue no faster than with 4-wave workgroups.)
     static constexpr int NQ = kNorm ? N / 256 : 1;        // float4 per lane of wave 0
-    static constexpr bool kBlkViaLds = (PRO == PRO_NORM) && NQ >= 4;   // coalesced loads + LDS transpose (see pro2_issue)
+    static constexpr bool kBlkViaLds = (PRO == PRO_NORM) && NQ >= Q3_BLK_LDS_MIN;   // coalesced loads + LDS transpose (see pro2_issue)
     float x[NP][EPT];
     float w[NP][EPT];
     v4f blk[NQ];

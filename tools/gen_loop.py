@@ -11,7 +11,7 @@ n = int(os.environ.get("Q3_NTOK", "32"))
 sh = ck.SHAPES[name]
 path = f"/tmp/q3_{name}.bin"
 ck.ensure_synthetic_checkpoint(path, sh, seed=1234)
-b = q3.TransformerBuilder(path).with_ctx_length(1024).with_strict(bool(int(os.environ.get("Q3_STRICT", "0"))))
+b = q3.TransformerBuilder(path).with_ctx_length(1024).with_strict(bool(int(os.environ.get("Q3_STRICT", "1"))))
 b = b.with_graph(not int(os.environ.get("Q3_EAGER", "0")))
 t = b.build()
 t.generate_greedy(5, 7, 4)
