@@ -241,7 +241,12 @@ __global__ __launch_bounds__(kBThreads) void k_bgemm(const BGemmArgs a) {
     const int ntasks = a.ntiles / RT;
     const size_t tile_v4 = (size_t)ng * NJ * 64;              // v4i per packed tile (weights or activations)
     const bool fold_thread = tid < NT * 256;                  // (stream, row) accumulator owner
-    const int f_stream = tid >> 4, f_row = tid & 15;
+    // The term tile of a (row tile, group, stream tile) is the MFMA result layout itself: lane l = 16 q + s of the producing
+    // wave writes its four rows (4q .. 4q+3 of stream s) as ONE contiguous 16-byte piece at float 4 l, and fold thread
+    // t reads float t & 255 -- both sides conflict-free.  (Round 2 stored [stream][row]: the 16 lanes of a quarter wave wrote
+    // 16-byte pieces 64 bytes apart -- an 8-way bank conflict; r03 PMC: SQ_LDS_BANK_CONFLICT = 55 % of SQ_LDS_IDX_ACTIVE,
+    // the LDS pipe busy 58 % of the w1|w3 launch.)
+    const int f_stream = ((tid >> 8) << 4) | ((tid >> 2) & 15), f_row = (((tid >> 6) & 3) << 2) | (tid & 3);
     unsigned long long best = 0ull;                           // EPI_LOGITS: running argmax key of f_stream (lanes with f_row == 0)
 
     struct Frag {
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(kBThreads) void k_bgemm(const BGemmArgs a) {
                         t.y = (float)c.y * wsv.y; t.y = t.y * xsc;
                         t.z = (float)c.z * wsv.z; t.z = t.z * xsc;
                         t.w = (float)c.w * wsv.w; t.w = t.w * xsc;
-                        *(v4f*)(terms + ((size_t)(rt * PG + gg) * NT * 16 + nt * 16 + s) * 16 + 4 * q) = t;
+                        *(v4f*)(terms + ((size_t)(rt * PG + gg) * NT + nt) * 256 + 4 * lane) = t;
                     }
                 }
             }
@@ -420,14 +425,23 @@ __global__ __launch_bounds__(kBThreads) void k_bgemm(const BGemmArgs a) {
             if (++p == nph) { p = 0; task += gridDim.x; }
     }
     if (EPI == EPI_LOGITS) {
-        // sampler.rs:57-59 (last maximum): max over the 16 row lanes of each stream, one slot per workgroup
-        for (int m = 1; m < 16; m <<= 1) {
+        // sampler.rs:57-59 (last maximum): max over the 16 rows of each stream -- 4 adjacent lanes (rows 4q .. 4q+3) in each of
+        // the 4 waves q of the stream tile -- one slot per workgroup
+        for (int m = 1; m < 4; m <<= 1) {
             const unsigned lo = __shfl_xor((unsigned)best, m);
             const unsigned hi = __shfl_xor((unsigned)(best >> 32), m);
             const unsigned long long o = ((unsigned long long)hi << 32) | lo;
             best = o > best ? o : best;
         }
-        if (fold_thread && f_row == 0 && f_stream < a.n_streams) a.slots[(size_t)f_stream * a.nslots + blockIdx.x] = best;
+        unsigned long long* red = (unsigned long long*)smem_raw;      // [stream][q]; the term tile is idle now
+        __syncthreads();
+        if (fold_thread && (tid & 3) == 0) red[f_stream * 4 + (f_row >> 2)] = best;
+        __syncthreads();
+        if (fold_thread && f_row == 0 && f_stream < a.n_streams) {
+            unsigned long long b = red[f_stream * 4];
+            for (int k = 1; k < 4; ++k) b = red[f_stream * 4 + k] > b ? red[f_stream * 4 + k] : b;
+            a.slots[(size_t)f_stream * a.nslots + blockIdx.x] = b;
+        }
     }
 }
 
