@@ -916,6 +916,54 @@ def test_device_sampler_large_vocab_and_prefill(q3, oracle, tmp_path_factory):
                 assert [first] + rest == want_tokens, f"batched={batched}"
 
 
+@pytest.mark.parametrize("pipeline", ["1", "0"])
+def test_device_sampler_pipelined_and_single_kernel_forms_agree(q3, oracle, pipeline, tmp_path_factory, monkeypatch):
+    """The engine's draw runs as a pipeline (exact sum | chip-wide normalise + histogram + compaction | sort + exact walks) or,
+    with Q3_SAMPLER_PIPELINE=0, as the single-workgroup kernel the batched sampler and q3_op_sample use: both must give the
+    oracle's tokens (sampler.rs:118-139), for a flat-ish and a peaked temperature, nucleus and plain multinomial."""
+    monkeypatch.setenv("Q3_SAMPLER_PIPELINE", pipeline)
+    ck = q3.checkpoint
+    shape = ck.SHAPES["qwen3-4b-dims-l2"]
+    path = str(tmp_path_factory.mktemp("samp2") / "4b-l2.bin")
+    ck.write_synthetic_checkpoint(path, shape, seed=11)
+    om = oracle.OracleModel(path)
+    with q3.TransformerBuilder(path).with_ctx_length(128).build() as t:
+        for temperature, topp in [(1.3, 0.9), (0.25, 0.95), (0.9, 0.3), (1.0, 1.0)]:
+            seed = 99 + int(temperature * 100)
+            smp = oracle.Sampler(shape.vocab_size, temperature, topp, seed)
+            om.reset()
+            tok, want = 7, []
+            for pos in range(12):
+                logits = np.array(om.forward(tok, pos), copy=True)
+                tok = smp.sample(logits)
+                want.append(tok)
+            t.reset_kv()
+            t.set_sampler(temperature, topp, seed)
+            got = t.generate_greedy(7, 0, 12)
+            assert got == want, f"T {temperature} top-p {topp} pipeline {pipeline}"
+
+
+def test_dense_prefill_with_the_batched_attention_kernel(q3, tmp_path_factory, monkeypatch):
+    """Q3_PREFILL_ATT_PF=0 keeps the dense matmuls but runs the block's attention on k_attn_gqa2 (the fallback for layouts
+    k_attn_pf2 does not cover): same cache rows and tokens as the sequential prompt loop."""
+    monkeypatch.setenv("Q3_PREFILL_ATT_PF", "0")
+    ck = q3.checkpoint
+    shape = ck.SHAPES["qwen3-0.6b-dims-l2"]
+    path = str(tmp_path_factory.mktemp("pf0") / "m.bin")
+    ck.write_synthetic_checkpoint(path, shape, seed=5)
+    prompt = ck.iter_prompt_tokens(shape, 4, 150)
+    with q3.TransformerBuilder(path).with_ctx_length(256).build() as t:
+        want = t.prefill(prompt, 0)
+        want_rest = t.generate_greedy(want, len(prompt), 4)
+        want_k, want_v = t.read_state("key"), t.read_state("value")
+    with q3.TransformerBuilder(path).with_ctx_length(256).build() as t:
+        got = t.prefill(prompt, 0, batched=True)
+        assert got == want
+        assert t.generate_greedy(got, len(prompt), 4) == want_rest
+        assert_biteq(t.read_state("key"), want_k, "key cache")
+        assert_biteq(t.read_state("value"), want_v, "value cache")
+
+
 def test_engine_runs_an_exported_hf_checkpoint(q3, oracle, tmp_path):
     """safetensors (F32 + BF16, LoRA adapter) -> export.py -> engine: logits bit-identical to the oracle on that file."""
     from qwen3_rs_amd import export
