@@ -916,19 +916,20 @@ def test_device_sampler_large_vocab_and_prefill(q3, oracle, tmp_path_factory):
                 assert [first] + rest == want_tokens, f"batched={batched}"
 
 
+@pytest.mark.parametrize("shape_name", ["qwen3-4b-dims-l2", "tiny-g64"])      # vocabulary 16,384 / 512 (one partial workgroup range)
 @pytest.mark.parametrize("pipeline", ["1", "0"])
-def test_device_sampler_pipelined_and_single_kernel_forms_agree(q3, oracle, pipeline, tmp_path_factory, monkeypatch):
+def test_device_sampler_pipelined_and_single_kernel_forms_agree(q3, oracle, pipeline, shape_name, tmp_path_factory, monkeypatch):
     """The engine's draw runs as a pipeline (exact sum | chip-wide normalise + histogram + compaction | sort + exact walks) or,
     with Q3_SAMPLER_PIPELINE=0, as the single-workgroup kernel the batched sampler and q3_op_sample use: both must give the
     oracle's tokens (sampler.rs:118-139), for a flat-ish and a peaked temperature, nucleus and plain multinomial."""
     monkeypatch.setenv("Q3_SAMPLER_PIPELINE", pipeline)
     ck = q3.checkpoint
-    shape = ck.SHAPES["qwen3-4b-dims-l2"]
-    path = str(tmp_path_factory.mktemp("samp2") / "4b-l2.bin")
+    shape = ck.SHAPES[shape_name]
+    path = str(tmp_path_factory.mktemp("samp2") / "m.bin")
     ck.write_synthetic_checkpoint(path, shape, seed=11)
     om = oracle.OracleModel(path)
-    with q3.TransformerBuilder(path).with_ctx_length(128).build() as t:
-        for temperature, topp in [(1.3, 0.9), (0.25, 0.95), (0.9, 0.3), (1.0, 1.0)]:
+    with q3.TransformerBuilder(path).with_ctx_length(96).build() as t:
+        for temperature, topp in [(1.3, 0.9), (0.25, 0.95), (0.9, 0.3), (1.0, 1.0), (4.0, 0.999)]:
             seed = 99 + int(temperature * 100)
             smp = oracle.Sampler(shape.vocab_size, temperature, topp, seed)
             om.reset()
