@@ -1248,13 +1248,14 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef const float __attribute__((address_space(4))) kfloat;      // constant address space: uniform loads are s_load
 constexpr int kWaitLgkm0 = 0xc07f;                                 // s_waitcnt lgkmcnt(0) only (vmcnt 63, expcnt 7)
-__host__ __device__ inline size_t attn_pf2_smem_bytes() { return 4 * (2 * (size_t)kG2Tch * (kG2Hd + kKPad)) + 32 * 8; }
+constexpr int kPfTch = 128;                                        // timesteps per staged chunk: two per lane in the score loop (half the barriers of 64)
+__host__ __device__ inline size_t attn_pf2_smem_bytes() { return 4 * (2 * (size_t)kPfTch * (kG2Hd + kKPad)) + 32 * 8; }
 __host__ __device__ constexpr int attn_pf2_threads(int kvm, int np) { return 64 * np * (kvm / 2); }
 
 template <int KVM, int NP>
 __global__ __launch_bounds__(64 * NP * (KVM / 2), NP * (KVM / 2) / 4) void k_attn_pf2(const AttnArgs a0) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int hd = kG2Hd, kld = hd + kKPad, TCH = kG2Tch, TILE = TCH * kld;
+    constexpr int hd = kG2Hd, kld = hd + kKPad, TCH = kPfTch, TILE = TCH * kld;
     constexpr int NPRW = KVM / 2, NW = NP * NPRW, NTHR = 64 * NW, NSL = TCH * (hd / 4) / NTHR;
     constexpr int DS = 16, TS = 16;                                // dims per score stage, timesteps per V stage
     static_assert(NSL >= 1 && hd % DS == 0 && TCH % TS == 0, "");
@@ -1312,18 +1313,20 @@ __global__ __launch_bounds__(64 * NP * (KVM / 2), NP * (KVM / 2) / 4) void k_att
         if (it == 8) GQA_STAMP(9);
         if (c0 + TCH < np_max) issue(kbase, c0 + TCH);
         if (live && c0 < np) {
-            const int t = c0 + lane;
+            // two timesteps per lane (rows lane and lane + 64 of the chunk): two packed chains on the same scalar q operands
+            const int t = c0 + lane, t1 = t + 64;
             const v4f* k4 = (const v4f*)(tile + lane * kld);
-            v2f d = {-0.0f, -0.0f};
+            const v4f* k4b = (const v4f*)(tile + (lane + 64) * kld);
+            v2f d = {-0.0f, -0.0f}, e = {-0.0f, -0.0f};
             float qc[2 * DS], qn[2 * DS];
-            v4f kc[DS / 4], kn[DS / 4];
+            v4f kc[DS / 4], kn[DS / 4], lc[DS / 4], ln[DS / 4];
             auto ldq = [&](float (&q)[2 * DS], int bb) {
 #pragma unroll
                 for (int i = 0; i < 2 * DS; ++i) q[i] = qk[2 * DS * bb + i];
             };
             ldq(qc, 0);
 #pragma unroll
-            for (int j = 0; j < DS / 4; ++j) kc[j] = k4[j];
+            for (int j = 0; j < DS / 4; ++j) { kc[j] = k4[j]; lc[j] = k4b[j]; }
 #pragma unroll
             for (int b = 0; b < hd / DS; ++b) {
                 __builtin_amdgcn_s_waitcnt(kWaitLgkm0);
@@ -1331,24 +1334,26 @@ __global__ __launch_bounds__(64 * NP * (KVM / 2), NP * (KVM / 2) / 4) void k_att
                 if (b + 1 < hd / DS) {
                     ldq(qn, b + 1);
 #pragma unroll
-                    for (int j = 0; j < DS / 4; ++j) kn[j] = k4[(DS / 4) * (b + 1) + j];
+                    for (int j = 0; j < DS / 4; ++j) { kn[j] = k4[(DS / 4) * (b + 1) + j]; ln[j] = k4b[(DS / 4) * (b + 1) + j]; }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < DS / 4; ++j) {
                     const float kk[4] = {kc[j].x, kc[j].y, kc[j].z, kc[j].w};
+                    const float ll[4] = {lc[j].x, lc[j].y, lc[j].z, lc[j].w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const v2f qq = {qc[8 * j + 2 * i], qc[8 * j + 2 * i + 1]};
                         d = d + qq * (v2f){kk[i], kk[i]};
+                        e = e + qq * (v2f){ll[i], ll[i]};
                     }
                 }
-                asm volatile("" : "+v"(d));                        // pure arithmetic is not ordered by sched_barrier: pin the chain to its stage
+                asm volatile("" : "+v"(d), "+v"(e));               // pure arithmetic is not ordered by sched_barrier: pin the chains to their stage
                 if (b + 1 < hd / DS) {
 #pragma unroll
                     for (int i = 0; i < 2 * DS; ++i) qc[i] = qn[i];
 #pragma unroll
-                    for (int j = 0; j < DS / 4; ++j) kc[j] = kn[j];
+                    for (int j = 0; j < DS / 4; ++j) { kc[j] = kn[j]; lc[j] = ln[j]; }
                 }
             }
             if (it == 8) GQA_STAMP(10);
@@ -1357,6 +1362,13 @@ __global__ __launch_bounds__(64 * NP * (KVM / 2), NP * (KVM / 2) / 4) void k_att
                 rows[t] = s0;
                 rows[(size_t)ast + t] = s1;
                 mx0 = fmaxf(mx0, s0);                              // running row maxima stay in registers (no pass over the row)
+                mx1 = fmaxf(mx1, s1);
+            }
+            if (t1 < np) {
+                const float s0 = e.x * scale, s1 = e.y * scale;
+                rows[t1] = s0;
+                rows[(size_t)ast + t1] = s1;
+                mx0 = fmaxf(mx0, s0);
                 mx1 = fmaxf(mx1, s1);
             }
         }
