@@ -68,13 +68,15 @@ namespace {
 #define Q3_CFG_NORM_QKV(N, WGT, EPT, RU, JU, PF) Q3_CFG(PRO_NORM, EPI_QKV, N, WGT, EPT, RU, JU, PF), Q3_CFG(PRO_EMBED_NORM, EPI_QKV, N, WGT, EPT, RU, JU, PF)
 const GemvCfg kGemvCfgs[] = {
     // --- QKV: RMSNorm_att + quantize + wq|wk|wv
-    Q3_CFG_NORM_QKV(1024, 1024, 1, 1, 1, 0), Q3_CFG_NORM_QKV(1024, 1024, 4, 1, 1, 0), Q3_CFG_NORM_QKV(1024, 512, 2, 2, 1, 0),
+    // (dim 1024, end of r03: the 512-thread / two-rows-per-wave forms lead the 1024-thread ones by 0.1 us per launch since the
+    // wave-0 block loads go through LDS; same-process A/B of the three 0.6B changes below: 1,552-1,567 -> 1,582-1,599 tok/s)
+    Q3_CFG_NORM_QKV(1024, 512, 2, 2, 1, 0), Q3_CFG_NORM_QKV(1024, 1024, 1, 1, 1, 0), Q3_CFG_NORM_QKV(1024, 1024, 4, 1, 1, 0),
     Q3_CFG_NORM_QKV(1024, 256, 4, 2, 1, 0),
     Q3_CFG_NORM_QKV(2560, 1024, 4, 1, 3, 0), Q3_CFG_NORM_QKV(2560, 1024, 4, 1, 3, 1), Q3_CFG_NORM_QKV(2560, 1024, 4, 2, 3, 0),
     Q3_CFG_NORM_QKV(4096, 1024, 4, 1, 4, 0), Q3_CFG_NORM_QKV(4096, 1024, 4, 1, 4, 1), Q3_CFG_NORM_QKV(4096, 1024, 4, 2, 4, 0),
     // --- W1|W3 + SwiGLU
-    Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 1024, 1, 2, 1, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 1024, 4, 2, 1, 0),
-    Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 512, 2, 4, 1, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 256, 4, 4, 1, 0),
+    Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 512, 2, 4, 1, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 1024, 1, 2, 1, 0),
+    Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 1024, 4, 2, 1, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 256, 4, 4, 1, 0),
     Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 1024, 4, 2, 3, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 512, 4, 2, 3, 1),
     Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 512, 4, 2, 3, 0),
     Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 1024, 4, 2, 4, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 512, 4, 2, 4, 1),
@@ -84,7 +86,7 @@ const GemvCfg kGemvCfgs[] = {
     Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 256, 4, 1, 4, 0), Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 256, 4, 2, 4, 0),
     Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 512, 4, 1, 4, 0),
     // --- quantize + W2 (and Wo of the long-context plan)
-    Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 512, 4, 1, 3, 0), Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 256, 4, 1, 3, 0),
+    Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 256, 4, 1, 3, 0), Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 512, 4, 1, 3, 0),
     Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 1024, 4, 1, 3, 0),
     Q3_CFG(PRO_QUANT, EPI_RESID, 9728, 1024, 4, 1, 2, 1), Q3_CFG(PRO_QUANT, EPI_RESID, 9728, 512, 4, 1, 2, 1),
     Q3_CFG(PRO_QUANT, EPI_RESID, 12288, 1024, 4, 1, 4, 1), Q3_CFG(PRO_QUANT, EPI_RESID, 12288, 512, 4, 1, 4, 1),
