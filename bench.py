@@ -232,6 +232,8 @@ def worker_main(args):
         out["roofline"] = None
         eng.close()
         return out
+    # which binary produced the numbers: the id baked into the loaded library next to the hash of the sources here
+    out["build_id"] = {"library": q3.load_library().q3_build_id().decode(), "sources": q3.source_build_id()}
 
     # ---- roofline of the dominant kernel: HIP events on the engine stream, one forward per rep (eager launches)
     reps = 20
@@ -285,7 +287,7 @@ def worker_main(args):
 # --------------------------------------------------------------------------------------------------------------
 def cpu_baseline(path, ctx, first_tok, first_pos, gpu_tokens, max_tokens=128, budget_s=25.0, one_thread_budget_s=10.0):
     """Oracle leg (test infrastructure used as the reported CPU baseline, kind "port").  Sample = the first
-    min(len(gpu_tokens), max_tokens) generated tokens of the same run (128 tokens), bounded by budget_s.
+    max_tokens (128) generated tokens of the same workload whatever --steps is, bounded by budget_s.
     Thread count: a sweep timed on 8 tokens per candidate, median of 3 repetitions each (a token is ~200 OpenMP
     fork-joins, so "all cores" loses to fewer threads on big hosts and a 2-token sweep was noise: VERDICT r2); the whole
     sweep table goes into the JSON so a run-to-run spread is visible.  The OpenMP runtime is pinned
@@ -297,7 +299,7 @@ def cpu_baseline(path, ctx, first_tok, first_pos, gpu_tokens, max_tokens=128, bu
     m = co.OracleModel(path, ctx)
     m.forward(first_tok, first_pos)           # untimed: page-in of the mmap'd checkpoint
     ncpu = os.cpu_count() or 1
-    want = min(len(gpu_tokens), max_tokens, ctx - first_pos)
+    want = min(max_tokens, ctx - first_pos)
     # more threads than ~64 never won on the 128-core / 256-thread GPU hosts, and with spinning workers
     # (OMP_WAIT_POLICY=active) an oversubscribed team takes minutes per token: the sweep stops at 64
     cands = sorted({c for c in (4, 8, 16, 32, 64) if c <= ncpu})
@@ -326,21 +328,39 @@ def cpu_baseline(path, ctx, first_tok, first_pos, gpu_tokens, max_tokens=128, bu
         sweep.append({"threads": c, "tok_s_median": round(rates_s[len(rates_s) // 2], 2), "tok_s_all": [round(r, 2) for r in rates]})
     best_c = max(sweep, key=lambda r: r["tok_s_median"])["threads"]     # the median: a count that is fast once and slow twice loses
 
-    toks, dt = run(best_c, want, budget_s)
-    toks1, dt1 = run(1, want, one_thread_budget_s)
+    # The reported figure: SURVEY 8d's 128 generated tokens whatever --steps was (the CPU generates its own greedy
+    # continuation; the first min(steps, 128) tokens are the ones compared with the GPU), median of 3 timed runs at
+    # the chosen thread count, after one untimed token that lets the OpenMP team of that size form and settle
+    # (20 tokens timed right behind a 64-thread spinning team disagreed with the sweep by 1.6x).
+    full = min(max_tokens, ctx - first_pos)
+    run(best_c, 1, 5.0)
+    runs = []
+    t_leg0 = time.perf_counter()
+    for _ in range(3):
+        if runs and time.perf_counter() - t_leg0 > budget_s:
+            break
+        tk, dt = run(best_c, full, budget_s)
+        runs.append((len(tk) / dt, tk, dt))
+    runs_sorted = sorted(runs, key=lambda r: r[0])
+    rate, toks, dt = runs_sorted[len(runs_sorted) // 2]
+    run(1, 1, 5.0)
+    toks1, dt1 = run(1, full, one_thread_budget_s)
     m.close()
     gpu = [int(t) for t in gpu_tokens]
-    match = toks == gpu[:len(toks)] and toks1 == gpu[:len(toks1)] and len(toks) > 0
-    return {"value": len(toks) / dt, "unit": "tokens/s", "cores": best_c, "kind": "port",
-            "sample": f"first {len(toks)} generated tokens of the same run ({dt:.1f} s) on {best_c} of {ncpu} host threads "
+    ncmp, ncmp1 = min(len(toks), len(gpu)), min(len(toks1), len(gpu))
+    match = ncmp > 0 and all(r[1][:ncmp] == gpu[:ncmp] for r in runs) and toks1[:ncmp1] == gpu[:ncmp1]
+    sweep_best = max(r["tok_s_median"] for r in sweep)
+    return {"value": rate, "unit": "tokens/s", "cores": best_c, "kind": "port",
+            "sample": f"{len(toks)} generated tokens of the same workload ({dt:.1f} s; median of {len(runs)} runs: "
+                      f"{[round(r[0], 1) for r in runs]}) on {best_c} of {ncpu} host threads "
                       f"(winner of the sweep below: {sweep_tokens} tokens per candidate, median of 3); C restatement of the Rust CPU "
                       f"path (no rustc in the image), OpenMP over rows/heads like rayon, threads pinned "
                       f"(OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}, OMP_PLACES={os.environ.get('OMP_PLACES')}, "
                       f"OMP_WAIT_POLICY={os.environ.get('OMP_WAIT_POLICY')})",
-            "thread_sweep": sweep,
+            "thread_sweep": sweep, "value_over_sweep_row": round(rate / sweep_best, 3),
             "one_thread": {"value": len(toks1) / dt1, "unit": "tokens/s", "cores": 1,
                            "sample": f"first {len(toks1)} generated tokens ({dt1:.1f} s) on 1 host thread"},
-            "tokens_compared": len(toks), "tokens_match_gpu": bool(match)}, match
+            "tokens_compared": ncmp, "tokens_match_gpu": bool(match)}, match
 
 
 def free_port():
@@ -444,7 +464,7 @@ def other_configs(args):
         ("config3 Qwen3-4B 2048-token prefill + 512-token decode",
          [py, os.path.join(tools, "bench_chat.py"), "--ckpt-dir", args.ckpt_dir]),
         ("config4 Qwen3-8B batch=32 concurrent decode streams",
-         [py, os.path.join(tools, "bench_batch.py"), "--ckpt-dir", args.ckpt_dir, "--steps", "128"]),
+         [py, os.path.join(tools, "bench_batch.py"), "--ckpt-dir", args.ckpt_dir, "--steps", "256"]),
         ("config5 DeepSeek-R1-0528-Qwen3-8B, one replica of the data-parallel set",
          [py, os.path.abspath(__file__), "--shape", "deepseek-r1-0528-qwen3-8b", "--steps", "32", "--warmup", "4",
           "--no-cpu-baseline", "--no-other-configs", "--ckpt-dir", args.ckpt_dir]),
@@ -482,6 +502,7 @@ def parent_main(args):
     out = spawn_workers(args, n)
     tokens = out.pop("_tokens")
     parity = None                      # None: not checked (no CPU leg); True/False: tokens compared
+    unchecked = False
     if n == 1 and not args.no_cpu_baseline and not args.stub_engine:
         try:
             cb, match = cpu_baseline(path, args.ctx, first_tok, first_pos, tokens)
@@ -489,11 +510,13 @@ def parent_main(args):
             parity = bool(match)
         except Exception as e:
             # the checker could not run (no gcc/make on the box, oracle build failure, OOM): an infrastructure failure,
-            # NOT a token mismatch -- the line says so and the exit code stays 0
-            log(f"[bench] cpu_baseline could not run: {e!r}")
+            # NOT a token mismatch -- the line says "parity": null + the error, and the exit code is 2 (1 = mismatch):
+            # a requested check that did not happen must not look like a pass
+            log(f"[bench] PARITY UNCHECKED: cpu_baseline could not run: {e!r}")
             out["cpu_baseline"] = None
             out["cpu_baseline_error"] = repr(e)[:300]
             parity = None
+            unchecked = True
         out["parity"] = parity
         if parity is False:
             log("[bench] FATAL: GPU tokens differ from the CPU oracle")
@@ -505,7 +528,7 @@ def parent_main(args):
     if n == 1 and args.shape == "qwen3-0.6b" and not args.no_other_configs and not args.stub_engine:
         out["other_configs"] = other_configs(args)
     print(json.dumps(out), flush=True)
-    return 1 if parity is False else 0
+    return 1 if parity is False else (2 if unchecked else 0)
 
 
 def main():

@@ -931,10 +931,7 @@ extern "C" {
 
 const char* q3_last_error(void) { return g_err; }
 uint32_t q3_abi_version(void) { return Q3_ABI_VERSION; }
-#ifndef Q3_BUILD_ID
-#define Q3_BUILD_ID "unknown"
-#endif
-const char* q3_build_id(void) { return Q3_BUILD_ID; }
+// q3_build_id(): csrc/q3_build_id.cpp (its own object, rebuilt whenever any source changes)
 
 int q3_parse_header(const uint8_t* data, size_t len, q3_config* out) {
     g_err[0] = 0;
@@ -1183,6 +1180,9 @@ int q3_reset_kv(q3_engine* e) {
     const size_t bytes = 4 * (size_t)e->cfg.n_layers * e->cfg.seq_len * e->cfg.n_kv_heads * e->cfg.head_dim;
     HIP_TRY(hipMemsetAsync(e->d_key, 0, bytes, e->stream));
     HIP_TRY(hipMemsetAsync(e->d_value, 0, bytes, e->stream));
+    // the classifier's {argmax cell, ticket} pair is self-clearing per token; a reset also recovers it after a launch that
+    // did not run to completion
+    if (e->d_next_cell) HIP_TRY(hipMemsetAsync(e->d_next_cell, 0, 16, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return Q3_OK;
 }

@@ -60,7 +60,7 @@ namespace {
 // Shape-specialised GEMV launches (k_gemv with N_T > 0): every (prologue, epilogue, contraction length) of the listed
 // models (0.6B dim 1024 / hidden 3072, 4B 2560 / 9728, 8B 4096 / 12288, all heads x head_dim 2048 / 4096)
 // has one or more tile / workgroup-width candidates; the first entry of a role is the default, Q3_CFG_<FAMILY>=k picks the
-// k-th (sweeps: tools/r03_cfg_sweep.sh), -1 forces the generic run-time-n kernel.  Anything not listed (test shapes,
+// k-th (sweeps: tools/cfg_sweep.py), -1 forces the generic run-time-n kernel.  Anything not listed (test shapes,
 // other group sizes) takes the generic path.
 // ------------------------------------------------------------------------------------------------
 #define Q3_CFG(PRO, EPI, N, WGT, EPT, RU, JU, PF) \
@@ -102,13 +102,9 @@ const GemvCfg kGemvCfgs[] = {
 namespace q3inst {
 const GemvCfg* find_cfg(int pro, int epi, int n, int G, int which) {
     if (G != 64 || which < 0) return nullptr;
-    const GemvCfg* last = nullptr;
     for (const GemvCfg& c : kGemvCfgs)
-        if (c.pro == pro && c.epi == epi && c.n == n) {
-            last = &c;
-            if (which-- == 0) return &c;
-        }
-    return last;                     // an index past the last candidate selects the last one
+        if (c.pro == pro && c.epi == epi && c.n == n && which-- == 0) return &c;
+    return nullptr;                  // no such candidate: the caller falls back to the generic kernel (a sweep sees "generic", not a mislabel)
 }
 
 

@@ -47,11 +47,18 @@ def q3():
         # (the id is read in a child process: a stale library must not stay mapped in this one)
         code = ("import ctypes,sys\ntry:\n L=ctypes.CDLL(sys.argv[1]); L.q3_build_id.restype=ctypes.c_char_p; print(L.q3_build_id().decode())\n"
                 "except Exception as e: print('unreadable')")
-        have = subprocess.run([sys.executable, "-c", code, lib], capture_output=True, text=True).stdout.strip() if os.path.exists(lib) else None
+        def read_id():
+            if not os.path.exists(lib):
+                return None
+            return subprocess.run([sys.executable, "-c", code, lib], capture_output=True, text=True).stdout.strip()
+        have = read_id()
         if have != want:
             if not shutil.which("make"):
                 raise RuntimeError(f"{lib} was built from other sources (build id {have}, sources {want}) and there is no make to rebuild it")
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "qwen3-rs_amd")])
+            have = read_id()
+            if have != want:
+                raise RuntimeError(f"{lib}: build id {have} after make, sources hash to {want}")
     qwen3_rs_amd.load_library()
     return qwen3_rs_amd
 

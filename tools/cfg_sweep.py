@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Sweep the specialised GEMV configurations (Q3_CFG_<FAMILY>=k, q3_engine.hip kGemvCfgs) of one model shape:
 for every family and candidate index, tok/s of the device-resident greedy loop and the family's launch period.
-usage: r03_sweep.py [shape] [ntok]   (env Q3_SWEEP="QKV:4,W13:4,WO:2,W2:3" overrides the candidate counts)"""
+usage: cfg_sweep.py [shape] [ntok]   (env Q3_SWEEP="QKV:4,W13:4,WO:2,W2:3" overrides the candidate counts)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "qwen3-rs_amd"))
