@@ -205,6 +205,8 @@ struct BGemmArgs {
     unsigned long long* stamps;  // developer timeline (Q3_DEV builds, block 0 thread 0): 5 stamps per phase
     unsigned long long* slots;   // LOGITS: [stream][nslots] argmax keys, one per wave of the launch
     int nslots;
+    int8_t* pack_q;          // k_dgemm SWIGLU: hq = quantize(hb) in packed operand order (W2's activation), or nullptr
+    float* pack_s;
 };
 
 // One workgroup (8 waves) per row task (RT row tiles of 16 rows), the contraction walked in phases of PG groups:
@@ -632,6 +634,359 @@ __global__ __launch_bounds__(kPgThreads) void k_pgemm(const BGemmArgs a) {
                     }
                 }
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched decode matmul, round 4: in-lane accumulation at 16-32 columns (k_dgemm).
+// k_bgemm splits K over the 8 waves of a workgroup and pays, per phase of 16-32 groups, a 64 KiB LDS term tile, two
+// barriers and a 16-32-term dependent fold behind LDS reads: with the weight loads compiled out its launches kept 70 % of
+// their time (profiles/r03_batch32_ablation.txt).  Here a WAVE owns one (16-row tile, 16-stream tile) accumulator tile for
+// the whole contraction exactly like k_pgemm -- per group one MFMA, four converts and three packed operations, the
+// g-ascending add of tensor.rs:53-60 done by the lane that holds the accumulator -- but sized for decode:
+//   * one row tile x one stream tile per wave (SwiGLU: the w1 and the w3 tile of 16 hidden units), so a 256-tile matrix
+//     gives 512 waves, two per CU on different SIMDs (k_pgemm's 2 x 2 tiles would leave half the CUs idle);
+//   * a DEEP register ring (16 groups = 16 KiB of weights per wave in flight): with one wave per SIMD the whole register
+//     file is there for it, and 512 waves x 16 KiB = 8 MB is what the HBM stream needs to stay busy;
+//   * the group scales of the wave's row tile(s) and stream tile travel as one float4 load per tile per DEPTH groups
+//     (chunk k + 1 requested at the head of ring iteration k, committed to a double-buffered wave-private LDS slice at its
+//     end) and are read back per group (ds_read_b128 / b32, broadcast): 2 VMEM instructions per group instead of 4, and
+//     no DPP broadcast.  (LDS-DMA for the scale tiles was tried first: with a global_load_lds anywhere in the function
+//     hipcc waits vmcnt(0) at the head of the ring loop -- the guide's caveat -- and the ring never runs ahead);
+//   * SwiGLU epilogue quantizes hb on the spot (tensor.rs:91-119): the four waves of a workgroup hold the 64 hidden units
+//     of one quantization group for the same 16 streams, so W2's operand leaves this kernel packed and the separate
+//     k_bquant_split<PRO_QUANT> launch (4.8 us per layer) is gone;
+//   * classifier epilogue: logits + per-stream argmax slot per wave (sampler.rs:57-59 last-maximum rule).
+// Same operations in the same order per (row, stream) as k_bgemm / k_gemv: bit-identical results.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned dg_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4i dg_as_v4i(dg_v4u v) { return (v4i){(int)v.x, (int)v.y, (int)v.z, (int)v.w}; }
+// B operand (the step's packed int8 activations) of a workgroup:
+//   BMODE 0  every wave pulls its B fragments from L2 inside its ring (waves numbered stream-tile-minor over the grid: the two
+//            stream tiles of a row tile are neighbouring waves and share the weight lines through L1)
+//   BMODE 1  the workgroup's waves work on ONE stream tile, staged in LDS once (ng KiB); the nst workgroups of a row group get
+//            block ids 8 apart -- the same XCD under the observed round-robin placement -- and share the weights through its L2
+//   BMODE 2  BOTH stream tiles in LDS (2 ng KiB, one workgroup per CU) and every wave computes both (PT = 2): a weight
+//            fragment is requested ONCE per CU and feeds two MFMAs.  (Measured first: the two stream tiles as two waves
+//            sharing the weight lines "through L1" -- both requests travel to L2, the CU's fill path carries the weights
+//            twice and saturates at ~32 GB/s per CU: W1|W3 25.7-27.5 us, classifier 148 us whatever the depth or balance.)
+// LDS per workgroup: [BMODE tiles] + per wave two chunks (double buffer) of DEPTH groups x 16 scales for each of its RT row
+// tiles and PT stream tiles + [2][4][16] group maxima of the fused quantizer
+__host__ __device__ inline size_t dgemm_smem_bytes(int rt, int waves, int depth, int bmode, int ng) {
+    const int pt = bmode == 2 ? 2 : 1;
+    return (size_t)bmode * ng * 1024 + 4 * ((size_t)waves * (rt + pt) * depth * 16 + 2 * 4 * 16);
+}
+
+// EPI_SWIGLU: RT = 2 (the w1 and the w3 tile of 16 hidden units); the fused quantizer (a.pack_q) needs the four unit tiles of a
+// quantization group of the hidden vector in one workgroup: 4 waves.
+// A wave walks its row tasks (rtask, rtask + rstride, ...) as ONE stream of groups: the ring, the scale chunks and the B
+// prefetch run across task boundaries (the classifier gives every wave ~10-40 tasks; restarting the ring per task left the
+// HBM stream idle for a round trip per 64 groups).  Needs ng % DEPTH == 0 (host).
+__device__ __attribute__((noinline)) void dg_fill_lds(const v4i* src, char* lds, int kib, int wave, int nwaves, int lane) {
+    for (int g = wave; g < kib; g += nwaves)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)g * 64 + lane),
+                                         (__attribute__((address_space(3))) void*)(lds + (size_t)g * 1024), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// developer ablation of k_dgemm, compile-time only (-DQ3_DABLATE=bits; results are wrong by construction, only time is read):
+// 1 no weight (A) loads, 2 no convert / scale / add chain, 4 no MFMAs, 8 no B fragment reads (LDS or L2)
+#ifdef Q3_DABLATE
+#define Q3_DABL(bit) ((Q3_DABLATE & (bit)) != 0)
+#else
+#define Q3_DABL(bit) false
+#endif
+template <int EPI, int DEPTH, int WAVES, int BMODE>
+__global__ __launch_bounds__(WAVES * 64) void k_dgemm(const BGemmArgs a) {
+    constexpr int RT = (EPI == EPI_SWIGLU) ? 2 : 1;
+    constexpr int PT = (BMODE == 2) ? 2 : 1;                     // stream tiles per wave
+    // scale chunk = the DEPTH groups of one ring iteration, requested in stage 0 of the iteration BEFORE (so it travels with
+    // the fragments of the same groups: a chunk requested only 8 groups ahead of its use made every commit wait out a full
+    // memory round trip and drained the ring to 8 groups whatever DEPTH was -- r04 ablation: 12 us of a 28 us W1|W3 launch),
+    // committed to the wave's single LDS slice in the last stage, after the last scale read of the current chunk
+    constexpr int CH = DEPTH;
+    static_assert(DEPTH * 4 <= 64, "a scale chunk is one float4 per lane at most");
+    constexpr int CF = CH * 16;                                  // floats per scale chunk (CH groups x 16 rows / streams)
+    static_assert(DEPTH % CH == 0, "whole chunks per ring iteration");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, s = lane & 15;
+    const int ng = a.ng;
+    const int nst = (a.n_streams + 15) >> 4;                    // stream tiles (1 or 2; BMODE 2: 2)
+    const size_t tile_v4 = (size_t)ng * 64;                      // v4i per packed tile (weights or activations)
+    float* lsc0 = (float*)(smem_raw + (size_t)BMODE * ng * 1024);
+    float* lsc = lsc0 + (size_t)wave * (RT + PT) * CF;          // [RT row tiles + PT stream tiles][CF]
+    float* red = lsc0 + (size_t)WAVES * (RT + PT) * CF;         // SwiGLU: [2 stream tiles][4 unit tiles][16 streams] maxima
+    const int nrt = a.ntiles / RT;                               // row tasks
+    int rtask, rstride, pt, slot, ri = wave;                     // ri: row task of the wave inside the workgroup
+    if constexpr (BMODE == 0) {
+        const int t = blockIdx.x * WAVES + wave;
+        rtask = t / nst;
+        pt = t - rtask * nst;
+        rstride = ((int)gridDim.x * WAVES) / nst;                // (gridDim.x * WAVES is a multiple of nst: host)
+        slot = rtask;
+    } else if constexpr (BMODE == 1) {
+        const int b = blockIdx.x;
+        int rg = b / nst;
+        pt = b - rg * nst;
+        if (nst == 2 && (b | 15) < (int)gridDim.x) { rg = (b >> 4) * 8 + (b & 7); pt = (b >> 3) & 1; }
+        rtask = rg * WAVES + wave;
+        rstride = ((int)gridDim.x / nst) * WAVES;
+        slot = rtask;
+    } else {
+        pt = 0;                                                  // (both stream tiles)
+        rtask = (int)blockIdx.x * WAVES + wave;
+        rstride = (int)gridDim.x * WAVES;
+        slot = rtask;
+    }
+    const v4i* lb = (const v4i*)smem_raw;                        // the stream tile(s) in LDS: [PT][ng][64 lanes]
+    const v4i* xbase = (const v4i*)a.xq + (size_t)pt * tile_v4;
+    const v4f* gxs = (const v4f*)(a.xs + (size_t)pt * ng * 16);  // (PT = 2: the second tile's scales follow at ng * 16 floats)
+    if constexpr (BMODE != 0) {
+        // activations -> LDS by LDS-DMA: ng KiB per stream tile, wave w copies every WAVES-th KiB, every request in flight at
+        // once (through registers it was 16 requests per wave and round trip: three dependent round trips before the first
+        // MFMA of the W1|W3 launch).  The copy lives in a function of its own: with a global_load_lds in THIS function hipcc
+        // waits vmcnt(0) at the head of the ring loop (see the header comment); a call boundary resets its bookkeeping.
+        const int kib = BMODE * ng;                              // BMODE 2: the two tiles are adjacent in a.xq
+        dg_fill_lds((const v4i*)a.xq + (BMODE == 2 ? 0 : (size_t)pt * tile_v4), smem_raw, kib, wave, WAVES, lane);
+        __syncthreads();
+    }
+    unsigned long long best[PT];                                 // EPI_LOGITS: running argmax key of stream s (over this lane's rows)
+#pragma unroll
+    for (int p = 0; p < PT; ++p) best[p] = 0ull;
+    if (rtask < nrt) {
+        const int ntk = (nrt - rtask + rstride - 1) / rstride;   // row tasks of this wave
+        const int sl = min(lane, CH * 4 - 1);                   // scale chunk: float4 index of this lane (upper lanes idle)
+        const int nsv = ng * 4;                                  // float4 per scale tile
+        // fragments by buffer loads: resource = the packed matrix (SGPRs), scalar offset = tile * ng KiB + group * 1 KiB, vector
+        // offset = lane * 16 -- no vector ALU in the address path (flat global loads cost a 64-bit v_lshl_add per request)
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.wq, 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, 0x7fffffff, 0x00020000);
+        const int tile_b = ng << 10;                             // bytes per packed tile
+        int cur = rtask, nxt = ntk > 1 ? rtask + rstride : rtask;        // current / next row task (a wave without a next one re-reads)
+        int k = 0;
+        v4f sc[RT + PT];                                         // scale chunk in flight (global -> registers -> LDS)
+        auto chunk_load = [&](int task, int c) {                 // chunk c = groups [c*CH, +CH) of row task `task`
+            const int f0 = c * (CH * 4) + sl;
+            const v4f* gws = (const v4f*)(a.ws + (size_t)(task * RT) * ng * 16);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) sc[rt] = (gws + (size_t)rt * nsv)[f0];
+#pragma unroll
+            for (int p = 0; p < PT; ++p) sc[RT + p] = (gxs + (size_t)p * nsv)[f0];
+        };
+        auto chunk_commit = [&]() {
+            if (lane < CH * 4) {
+#pragma unroll
+                for (int kk = 0; kk < RT + PT; ++kk) ((v4f*)(lsc + (size_t)kk * CF))[lane] = sc[kk];
+            }
+        };
+        v4i fa[DEPTH][RT], fb[BMODE != 0 ? 1 : DEPTH];
+        auto load_ab = [&](int slot_, int task, int g) {
+            const int goff = g << 10;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                fa[slot_][rt] = Q3_DABL(1) ? (v4i){lane, goff, task, rt}
+                                           : dg_as_v4i(__builtin_amdgcn_raw_buffer_load_b128(wr, lane << 4, (task * RT + rt) * tile_b + goff, 0));
+            if constexpr (BMODE == 0) fb[slot_] = Q3_DABL(8) ? (v4i){lane, goff, 1, 2} : dg_as_v4i(__builtin_amdgcn_raw_buffer_load_b128(xr, lane << 4, goff, 0));
+        };
+        chunk_load(cur, 0);                                      // oldest loads
+#pragma unroll
+        for (int d = 0; d < DEPTH - 1; ++d) load_ab(d, cur, d);
+        chunk_commit();                                          // (counted wait: the ring fill stays in flight)
+        wave_lds_sync();
+        v4f acc[RT][PT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int p = 0; p < PT; ++p) acc[rt][p] = (v4f){-0.0f, -0.0f, -0.0f, -0.0f};   // Iterator::sum::<f32>() identity
+        v4i cc[RT][PT], cn[RT][PT];
+        v4f wsc[RT], wsn[RT];
+        float xsc[PT], xsn[PT];
+        v4i bc[PT], bn[PT];                                      // BMODE 1/2: B fragments of the group whose MFMAs are issued next
+#pragma unroll
+        for (int p = 0; p < PT; ++p) bc[p] = bn[p] = (v4i){0, 0, 0, 0};
+        auto bfrag = [&](v4i (&b)[PT], int g) {
+            if constexpr (BMODE != 0) {
+#pragma unroll
+                for (int p = 0; p < PT; ++p) b[p] = Q3_DABL(8) ? (v4i){lane, g, p, 3} : lb[(size_t)p * tile_v4 + (size_t)(g >= ng ? g - ng : g) * 64 + lane];
+            }
+        };
+        auto mfma_group = [&](v4i (&c)[RT][PT], int slot_, const v4i (&bl)[PT]) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int p = 0; p < PT; ++p)
+                    c[rt][p] = Q3_DABL(4) ? fa[slot_][rt] + (BMODE != 0 ? bl[p] : fb[BMODE != 0 ? 0 : slot_])
+                                          : __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[slot_][rt], BMODE != 0 ? bl[p] : fb[BMODE != 0 ? 0 : slot_], (v4i){0, 0, 0, 0}, 0, 0, 0);
+        };
+        auto scales = [&](v4f (&w)[RT], float (&x)[PT], int u) {      // scales of group u of the chunk in LDS
+            const float* b0 = lsc;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) w[rt] = *(const v4f*)(b0 + rt * CF + u * 16 + 4 * q);
+#pragma unroll
+            for (int p = 0; p < PT; ++p) x[p] = b0[(RT + p) * CF + u * 16 + s];
+        };
+        auto math_group = [&](const v4i (&cg)[RT][PT], const v4f (&w)[RT], const float (&x)[PT]) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int p = 0; p < PT; ++p) {
+                    const v4i c = cg[rt][p];
+                    if (Q3_DABL(2)) { acc[rt][p].x = __int_as_float(__float_as_int(acc[rt][p].x) ^ c.x ^ c.y ^ c.z ^ c.w); continue; }
+                    // tensor.rs:59  ((dot as f32) * ws) * xs, then the g-ascending add; pairs (rows 4q, 4q+1), (4q+2, 4q+3)
+                    pk2 t01 = (pk2){(float)c.x, (float)c.y} * (pk2){w[rt].x, w[rt].y};
+                    pk2 t23 = (pk2){(float)c.z, (float)c.w} * (pk2){w[rt].z, w[rt].w};
+                    asm("" : "+v"(t01)); asm("" : "+v"(t23));
+                    t01 = t01 * (pk2){x[p], x[p]}; t23 = t23 * (pk2){x[p], x[p]};
+                    asm("" : "+v"(t01)); asm("" : "+v"(t23));
+                    v4f& ac = acc[rt][p];
+                    pk2 a01 = (pk2){ac.x, ac.y} + t01, a23 = (pk2){ac.z, ac.w} + t23;
+                    asm("" : "+v"(a01)); asm("" : "+v"(a23));
+                    ac.x = a01.x; ac.y = a01.y; ac.z = a23.x; ac.w = a23.y;
+                }
+        };
+        auto rotate = [&]() {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                wsc[rt] = wsn[rt];
+#pragma unroll
+                for (int p = 0; p < PT; ++p) cc[rt][p] = cn[rt][p];
+            }
+#pragma unroll
+            for (int p = 0; p < PT; ++p) { xsc[p] = xsn[p]; if constexpr (BMODE != 0) bc[p] = bn[p]; }
+        };
+        // ---- epilogue of row task `task`: lane (s, q) owns out[stream (pt + p)*16 + s][rows 4q .. 4q+3 of the row tile]
+        auto epilogue = [&](int task) {
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                const int tp = pt + p;                            // stream tile
+                const int sb = tp * 16 + s;
+                const bool live = sb < a.n_streams;
+                if constexpr (EPI == EPI_SWIGLU) {
+                    // packed tiles alternate w1 | w3 of the same 16 hidden units            layers.rs:468-475
+                    v4f o;
+                    const v4f g1 = acc[0][p], up = acc[RT - 1][p];
+                    { const float den = 1.0f + q3_expf(-g1.x); o.x = (g1.x * (1.0f / den)) * up.x; }
+                    { const float den = 1.0f + q3_expf(-g1.y); o.y = (g1.y * (1.0f / den)) * up.y; }
+                    { const float den = 1.0f + q3_expf(-g1.z); o.z = (g1.z * (1.0f / den)) * up.z; }
+                    { const float den = 1.0f + q3_expf(-g1.w); o.w = (g1.w * (1.0f / den)) * up.w; }
+                    if (a.out0 != nullptr && live) *(v4f*)(a.out0 + (size_t)sb * a.out0_stride + (size_t)task * 16 + 4 * q) = o;
+                    if (a.pack_q != nullptr) {
+                        // hq = quantize(hb) (tensor.rs:91-119) for W2: group = the 64 hidden units of this workgroup (unit tile =
+                        // wave), stream s; the packed operand piece (q' = wave, s) takes this lane's four bytes at 4q.  (host: one
+                        // row task per wave, four waves per workgroup)
+                        float* rd = red + p * 64;
+                        float m = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
+                        m = fmaxf(m, __shfl_xor(m, 16));
+                        m = fmaxf(m, __shfl_xor(m, 32));
+                        if (q == 0) rd[ri * 16 + s] = m;
+                        __syncthreads();
+                        m = fmaxf(fmaxf(rd[s], rd[16 + s]), fmaxf(rd[32 + s], rd[48 + s]));
+                        const float scale = m / 127.0f;
+                        int q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+                        if (scale != 0.0f) {
+                            q0 = quant_round_i8(o.x / scale);
+                            q1 = quant_round_i8(o.y / scale);
+                            q2 = quant_round_i8(o.z / scale);
+                            q3 = quant_round_i8(o.w / scale);
+                        }
+                        const int gh = task >> 2, ngh = a.ntiles >> 3;               // group index / groups per row of W2's contraction
+                        if (live) {
+                            int8_t* dst = a.pack_q + ((((size_t)tp * ngh + gh) * 64 + (ri * 16 + s)) * 16 + 4 * q);
+                            *(int*)dst = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((q3 & 0xff) << 24);
+                            if (ri == 0 && q == 0) a.pack_s[((size_t)tp * ngh + gh) * 16 + s] = scale;
+                        }
+                    }
+                } else {
+                    const int r0 = task * 16 + 4 * q;
+                    const v4f o = acc[0][p];
+                    if constexpr (EPI == EPI_QKV) {
+                        if (live) {
+                            float* dst;
+                            if (r0 < a.rows0) dst = a.out0 + (size_t)sb * a.out0_stride + r0;
+                            else if (r0 < a.rows0 + a.rows1) dst = a.out1 + (size_t)sb * a.out1_stride + (r0 - a.rows0);
+                            else dst = a.out2 + (size_t)sb * a.out2_stride + (size_t)a.st[sb].pos * a.pos_stride + (r0 - a.rows0 - a.rows1);
+                            *(v4f*)dst = o;
+                        }
+                    } else if constexpr (EPI == EPI_RESID) {
+                        if (live) {
+                            v4f* dst = (v4f*)(a.out0 + (size_t)sb * a.out0_stride + r0);
+                            v4f x = *dst;
+                            x.x = x.x + o.x; x.y = x.y + o.y; x.z = x.z + o.z; x.w = x.w + o.w;      // layers.rs:249-259
+                            *dst = x;
+                        }
+                    } else if constexpr (EPI == EPI_LOGITS) {
+                        if (live) {
+                            if (a.out0 != nullptr) *(v4f*)(a.out0 + (size_t)sb * a.out0_stride + r0) = o;
+                            const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const unsigned long long key = ((unsigned long long)total_order_key(ov[i]) << 32) | (unsigned)(r0 + i);
+                                best[p] = key > best[p] ? key : best[p];
+                            }
+                        }
+                    } else {
+                        if (live) *(v4f*)(a.out0 + (size_t)sb * a.out0_stride + r0) = o;
+                    }
+                }
+            }
+        };
+        // software pipeline (k_pgemm's): stage u requests the group DEPTH - 1 ahead, issues the MFMAs and the LDS scale reads
+        // of the next group (BMODE 1/2: and the B fragment of the one after), then runs the convert / scale / add chain of
+        // its own group while those are in flight.  An iteration = DEPTH groups of one row task; it also carries the NEXT
+        // iteration's scale chunk: requested in stage 0, committed to the other LDS buffer in the last stage, just before
+        // that chunk's first scales are read.  In the last iteration of a row task "ahead" means the next row task.
+        bfrag(bc, 0);
+        mfma_group(cc, 0, bc);
+        bfrag(bc, 1);
+        scales(wsc, xsc, 0);
+        int g0 = 0;
+        for (;;) {
+            const bool last = g0 + DEPTH == ng;                  // wave-uniform
+            const int ptask = last ? nxt : cur;                  // task / first group of the requests that run past this iteration
+            const int pg0 = last ? -DEPTH : g0;
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) {
+                if (u == 0) load_ab(DEPTH - 1, cur, g0 + DEPTH - 1);
+                else load_ab(u - 1, ptask, pg0 + u + DEPTH - 1);
+                if (u == 0) chunk_load(ptask, (pg0 + DEPTH) / CH);    // the next iteration's scales (maybe the next task's chunk 0)
+                mfma_group(cn, (u + 1) % DEPTH, bc);
+                bfrag(bn, g0 + u + 2);
+                if (u == DEPTH - 1) { wave_lds_sync(); chunk_commit(); wave_lds_sync(); scales(wsn, xsn, 0); }
+                else scales(wsn, xsn, u + 1);
+                math_group(cc, wsc, xsc);
+                rotate();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            g0 += DEPTH;
+            if (last) {
+                epilogue(cur);
+                if (++k == ntk) break;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int p = 0; p < PT; ++p) acc[rt][p] = (v4f){-0.0f, -0.0f, -0.0f, -0.0f};
+                g0 = 0;
+                cur = nxt;
+                nxt = k + 1 < ntk ? cur + rstride : cur;
+            }
+        }
+    }
+    if constexpr (EPI == EPI_LOGITS) {
+        // sampler.rs:57-59 (last maximum): max over the rows this wave saw for stream s -- lanes s, s+16, s+32, s+48 --
+        // one slot per wave of a stream tile (slot = its first row task: < rstride); k_next_batch reduces the slots
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            unsigned long long bp = best[p];
+#pragma unroll
+            for (int m = 16; m < 64; m <<= 1) {
+                const unsigned lo = __shfl_xor((unsigned)bp, m);
+                const unsigned hi = __shfl_xor((unsigned)(bp >> 32), m);
+                const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+                bp = o > bp ? o : bp;
+            }
+            const int sbl = (pt + p) * 16 + s;
+            if (q == 0 && sbl < a.n_streams && slot < a.nslots) a.slots[(size_t)sbl * a.nslots + slot] = bp;
         }
     }
 }

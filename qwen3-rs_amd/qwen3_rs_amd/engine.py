@@ -66,11 +66,12 @@ _lib: Optional[C.CDLL] = None
 
 
 def source_build_id() -> str:
-    """The id `make` bakes into the library: sha256 over csrc/* and include/qwen3_hip.h in sorted order (first 16 hex digits)."""
+    """The id `make` bakes into the library: sha256 over csrc/* (sorted), include/qwen3_hip.h and the Makefile (compiler flags) -- first 16 hex digits."""
     import glob
     import hashlib
     h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(_DIST_DIR, "csrc", "*"))) + [os.path.join(os.path.dirname(_DIST_DIR), "include", "qwen3_hip.h")]
+    files = sorted(glob.glob(os.path.join(_DIST_DIR, "csrc", "*"))) + [os.path.join(os.path.dirname(_DIST_DIR), "include", "qwen3_hip.h"),
+                                                                          os.path.join(_DIST_DIR, "Makefile")]
     for f in files:
         with open(f, "rb") as fh:
             h.update(fh.read())

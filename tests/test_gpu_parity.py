@@ -555,11 +555,22 @@ def test_batched_prefill_kv_and_token_vs_oracle(q3, oracle, tmp_path_factory):
             assert_biteq(t.read_state("value", layer * 128 * kvd, 70 * kvd), ov[layer].reshape(-1)[:70 * kvd], f"value rows layer {layer}")
 
 
-def test_batched_decode_8b_layer_dims_vs_forward_and_oracle(q3, oracle):
+# k_dgemm launch forms (round 4; the plan is built at batch_init, the knobs are read from the environment then): the default
+# (residual launches), every family in-lane with the fused hq quantizer and both ring depths, the one-stream-tile-per-workgroup
+# and three-wave W1|W3 forms, and k_bgemm everywhere
+_DGEMM_FORMS = [{}, {"Q3_DGEMM_FAMILIES": "15"}, {"Q3_DGEMM_FAMILIES": "15", "Q3_DGEMM_DEEP": "0"},
+                {"Q3_DGEMM_FAMILIES": "15", "Q3_DGEMM_W13_MODE": "0"}, {"Q3_DGEMM_FAMILIES": "15", "Q3_DGEMM_W13_MODE": "2"},
+                {"Q3_DGEMM_FAMILIES": "15", "Q3_DGEMM_BLDS": "0"}, {"Q3_BATCH_DGEMM": "0"}]
+
+
+@pytest.mark.parametrize("form", range(len(_DGEMM_FORMS)))
+def test_batched_decode_8b_layer_dims_vs_forward_and_oracle(q3, oracle, form, monkeypatch):
     """BASELINE config 4's matrix shapes on the batched path: row lengths 4096 / 12288 (64 and 192 groups per row), 32
     heads over 8 kv heads, untied classifier -- 2 layers, reduced vocabulary.  32 streams x 8 steps: every stream's
     logits bit-identical to q3_forward on the same (token, pos) sequence for the first 4 streams, and 2 streams
-    against the oracle."""
+    against the oracle.  Run for every matmul form of the batched path (_DGEMM_FORMS)."""
+    for k, v in _DGEMM_FORMS[form].items():
+        monkeypatch.setenv(k, v)
     ck = q3.checkpoint
     name = "qwen3-8b-dims-l2"
     shape = ck.SHAPES[name]

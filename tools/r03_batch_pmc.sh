@@ -15,5 +15,5 @@ import json,glob
 for f in sorted(glob.glob("$out/pass*.json")):
     d=json.load(open(f))
     for k,v in d["kernels"].items():
-        if "bgemm" in k or "bquant" in k or "attn" in k: print(f.split('/')[-1], k[:44], {a.replace('avg_',''):round(b) for a,b in v.items()})
+        if "gemm" in k or "bquant" in k or "attn" in k: print(f.split('/')[-1], k[:44], {a.replace('avg_',''):round(b) for a,b in v.items()})
 PYEOF
