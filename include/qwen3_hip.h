@@ -104,6 +104,11 @@ int q3_generate_greedy(q3_engine* e, size_t first_token, size_t first_pos, size_
  * Tokens are identical to q3_generate_greedy.  bench.py reports this as `forward_surface`. */
 int q3_host_generate(q3_engine* e, size_t first_token, size_t first_pos, size_t n_tokens, int32_t* out_tokens, double* seconds);
 
+/* The host half of generate_next_token as q3_host_generate runs it (no device involved): copy n logits to `copy`
+ * (generation.rs:160 `logits.to_vec()`; may be NULL) and return Sampler::sample_argmax of them -- the index of the LAST maximum
+ * under f32::total_cmp (sampler.rs:57-59, Iterator::max_by).  One vectorised pass (AVX2 when the host has it). */
+size_t q3_host_sample_argmax(const float* logits, size_t n, float* copy);
+
 /* The prompt loop of `chat` (handle_user_turn, generation.rs:116-123) kept on the device: every prompt token is
  * forwarded in order at first_pos, first_pos+1, ... (sequential prefill: identical K/V rows and logits to n calls
  * of q3_forward), the per-token sample is discarded, and the argmax after the LAST prompt token -- the first

@@ -547,7 +547,12 @@ __global__ __launch_bounds__(kPgThreads) void k_pgemm(const BGemmArgs a) {
 #pragma unroll
                 for (int pt = 0; pt < PT; ++pt) {
                     const v4i c = cg[rt][pt];
-                    const float xsc = fxs[slot][pt];
+                    // the position scale as a REAL register pair {xs, xs}, materialised here.  Left to the compiler the packed
+                    // multiply broadcast one half of whatever 64-bit pair held xs (op_sel) and so formally read the partner
+                    // register too -- usually the scale of a slot still in flight, and hipcc waited for that slot's loads
+                    // (r04 disassembly: s_waitcnt vmcnt(6) with 28 loads in the ring, vmcnt(12-20) with 40)
+                    pk2 xbc = (pk2){fxs[slot][pt], fxs[slot][pt]};
+                    asm("" : "+v"(xbc));
                     // tensor.rs:59  ((dot as f32) * ws) * xs, then the g-ascending add.  The pairs are chosen by hand -- (rows 4q,
                     // 4q+1) and (4q+2, 4q+3) of one (row tile, position tile): their scales are the two halves of the v4f the ring
                     // loaded, xs is broadcast by op_sel -- three packed operations per pair.  Every value passes through an opaque
@@ -556,7 +561,7 @@ __global__ __launch_bounds__(kPgThreads) void k_pgemm(const BGemmArgs a) {
                     pk2 t01 = (pk2){(float)c.x, (float)c.y} * (pk2){wsv.x, wsv.y};
                     pk2 t23 = (pk2){(float)c.z, (float)c.w} * (pk2){wsv.z, wsv.w};
                     asm("" : "+v"(t01)); asm("" : "+v"(t23));
-                    t01 = t01 * (pk2){xsc, xsc}; t23 = t23 * (pk2){xsc, xsc};
+                    t01 = t01 * xbc; t23 = t23 * xbc;
                     asm("" : "+v"(t01)); asm("" : "+v"(t23));
                     v4f& ac = acc[rt][pt];
                     pk2 a01 = (pk2){ac.x, ac.y} + t01, a23 = (pk2){ac.z, ac.w} + t23;

@@ -8,6 +8,9 @@
 //   Qwen3Transformer::forward            qwen3.rs:62-79           -> Engine::enqueue_forward (kernel chain)
 // There is deliberately no CPU fallback anywhere in this file.
 #include <hip/hip_runtime.h>
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#endif
 
 #include <errno.h>
 #include <fcntl.h>
@@ -869,8 +872,17 @@ int q3_engine::capture() {
         for (int lng = 0; lng < 2; ++lng) {
             HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
             HIP_TRY(hipMemcpyAsync(d_state, h_state, sizeof(State), hipMemcpyHostToDevice, stream));
-            for (const Launch& L : (lng ? plan_long : plan)) launch_one(L, this);
-            HIP_TRY(hipMemcpyAsync(h_logits, d_logits, lbytes, hipMemcpyDeviceToHost, stream));
+            // Q3_FWD_LOGITS_HOST=1: the classifier stores its logits straight into the pinned host buffer (device-visible,
+            // fine-grained) and the download node disappears (SURVEY section 7 "Logits egress"; measured in DESIGN section 7)
+            const bool host_out = env_int("Q3_FWD_LOGITS_HOST", 0) != 0;
+            for (const Launch& L : (lng ? plan_long : plan)) {
+                if (host_out && L.fam == F_LMHEAD && !L.is_attn && !L.is_next) {
+                    Launch M = L;
+                    M.ga.seg[0].out = h_logits;
+                    launch_one(M, this);
+                } else launch_one(L, this);
+            }
+            if (!host_out) HIP_TRY(hipMemcpyAsync(h_logits, d_logits, lbytes, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamEndCapture(stream, lng ? &graph_fwd_long : &graph_fwd));
             HIP_TRY(hipGraphInstantiate(lng ? &graph_fwd_long_exec : &graph_fwd_exec, lng ? graph_fwd_long : graph_fwd, nullptr, nullptr, 0));
         }
@@ -1249,37 +1261,110 @@ int q3_profile(q3_engine* e, size_t token, size_t pos, int reps, float* ms, int3
 // (last maximum under total_cmp, sampler.rs:57-59) -> feed back.  *seconds follows TokenMetrics (generation.rs:198-233):
 // the clock starts before the first forward and stops after the last sample.  This is what a Rust caller of the
 // Transformers::Qwen3Hip shim observes; the logits cross PCIe every token.
+}  // extern "C"
+
+namespace {
+// copy n floats and return the index of the LAST maximum under f32::total_cmp (key = bits ^ ((bits >> 31) & 0x7fffffff) as
+// int32: negative floats order reversed).  AVX2 when the host has it (8 keys per step, streaming loads of the pinned
+// buffer), scalar otherwise.
+#if !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target("avx2"))) size_t copy_argmax_last_avx2(const float* src, float* dst, size_t n) {
+    // ONE pass: 8 lanes each keep (best key, index of its last occurrence); `key >= best` replaces, so a later equal key wins.
+    // dst is 32-byte aligned (caller): non-temporal stores, the copy is not read again here.
+    const __m256i m7f = _mm256_set1_epi32(0x7fffffff);
+    __m256i best = _mm256_set1_epi32(INT32_MIN), bidx = _mm256_setzero_si256();
+    __m256i cur = _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7);
+    const __m256i step = _mm256_set1_epi32(8);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const __m256i b = _mm256_loadu_si256((const __m256i*)(src + i));
+        _mm256_stream_si256((__m256i*)(dst + i), b);
+        const __m256i key = _mm256_xor_si256(b, _mm256_and_si256(_mm256_srai_epi32(b, 31), m7f));
+        const __m256i lt = _mm256_cmpgt_epi32(best, key);             // best > key: keep
+        best = _mm256_max_epi32(best, key);
+        bidx = _mm256_blendv_epi8(cur, bidx, lt);
+        cur = _mm256_add_epi32(cur, step);
+    }
+    _mm_sfence();
+    alignas(32) int32_t kk[8], ii[8];
+    _mm256_store_si256((__m256i*)kk, best);
+    _mm256_store_si256((__m256i*)ii, bidx);
+    int32_t best_key = INT32_MIN;
+    size_t best_i = 0;
+    for (int l = 0; l < 8; ++l)
+        if (kk[l] > best_key || (kk[l] == best_key && (size_t)ii[l] > best_i)) { best_key = kk[l]; best_i = (size_t)ii[l]; }
+    for (; i < n; ++i) {
+        int32_t b;
+        memcpy(&b, src + i, 4);
+        dst[i] = src[i];
+        const int32_t key = b ^ ((b >> 31) & 0x7fffffff);
+        if (key >= best_key) { best_key = key; best_i = i; }
+    }
+    return best_i;
+}
+#endif
+size_t host_copy_argmax_last(const float* src, float* dst, size_t n) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return copy_argmax_last_avx2(src, dst, n);
+#endif
+    const int32_t* sb = (const int32_t*)src;
+    int32_t best_key = INT32_MIN;
+    size_t best_i = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const int32_t b = sb[i];
+        dst[i] = src[i];
+        const int32_t key = b ^ ((b >> 31) & 0x7fffffff);
+        if (key >= best_key) { best_key = key; best_i = i; }
+    }
+    return best_i;
+}
+}  // namespace
+
+extern "C" {
+
+size_t q3_host_sample_argmax(const float* logits, size_t n, float* copy) {
+    if (!logits || n == 0) return 0;
+    if (copy && ((uintptr_t)copy & 31) == 0) return host_copy_argmax_last(logits, copy, n);
+    // no (or an unaligned) destination: the same pass into a scratch block, then a plain copy
+    std::vector<float> tmp(n + 16);
+    float* al = (float*)(((uintptr_t)tmp.data() + 31) & ~(uintptr_t)31);
+    const size_t r = host_copy_argmax_last(logits, al, n);
+    if (copy) memcpy(copy, al, 4 * n);
+    return r;
+}
+
 int q3_host_generate(q3_engine* e, size_t first_token, size_t first_pos, size_t n_tokens, int32_t* out_tokens, double* seconds) {
     g_err[0] = 0;
     if (!e || (!out_tokens && n_tokens)) return fail(Q3_ERR_ARG, "null argument");
     if (first_pos + n_tokens > (size_t)e->cfg.seq_len)
         return fail(Q3_ERR_ARG, "first_pos %zu + n_tokens %zu exceeds seq_len %d", first_pos, n_tokens, e->cfg.seq_len);
     const size_t V = (size_t)e->cfg.vocab_size;
-    std::vector<float> copy(V);
-    struct timespec t0, t1;
+    std::vector<float> copy_store(V + 16);
+    float* const copy = (float*)(((uintptr_t)copy_store.data() + 31) & ~(uintptr_t)31);      // 32-byte aligned (non-temporal stores)
+    static const bool dbg = getenv("Q3_DEBUG_TIMING") != nullptr;
+    double t_fwd = 0.0, t_host = 0.0;
+    struct timespec t0, t1, ta, tb, tc;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     size_t token = first_token;
     for (size_t k = 0; k < n_tokens; ++k) {
+        if (dbg) clock_gettime(CLOCK_MONOTONIC, &ta);
         const float* lg = q3_forward(e, token, first_pos + k);
         if (!lg) return Q3_ERR_HIP;
-        memcpy(copy.data(), lg, 4 * V);                                   // generation.rs:160  logits.to_vec()
-        // Iterator::max_by(total_cmp): the LAST maximum under the IEEE total order (sampler.rs:57-59).  Two passes the compiler
-        // vectorises: the maximum key (a plain max reduction over int32 keys), then a scan from the END for its first match.
-        const int32_t* bits = (const int32_t*)copy.data();
-        int32_t best_key = INT32_MIN;
-        for (size_t i = 0; i < V; ++i) {
-            const int32_t b = bits[i];
-            const int32_t key = b ^ ((b >> 31) & 0x7fffffff);            // total_cmp key: negative floats order reversed
-            best_key = key > best_key ? key : best_key;
-        }
-        size_t best = 0;
-        for (size_t i = V; i-- > 0;) {
-            const int32_t b = bits[i];
-            if ((b ^ ((b >> 31) & 0x7fffffff)) == best_key) { best = i; break; }
-        }
+        if (dbg) clock_gettime(CLOCK_MONOTONIC, &tb);
+        // generation.rs:160 `logits.to_vec()` and Sampler::sample_argmax in ONE pass over the pinned buffer: copy + the maximum
+        // total_cmp key (sampler.rs:57-59: Iterator::max_by keeps the LAST maximum under the IEEE total order), then a scan
+        // from the END of the copy for its first match
+        const size_t best = host_copy_argmax_last(lg, copy, V);
         out_tokens[k] = (int32_t)best;
         token = best;
+        if (dbg) {
+            clock_gettime(CLOCK_MONOTONIC, &tc);
+            t_fwd += (tb.tv_sec - ta.tv_sec) * 1e6 + (tb.tv_nsec - ta.tv_nsec) * 1e-3;
+            t_host += (tc.tv_sec - tb.tv_sec) * 1e6 + (tc.tv_nsec - tb.tv_nsec) * 1e-3;
+        }
     }
+    if (dbg && n_tokens) fprintf(stderr, "[q3] host_generate: q3_forward %.1f us/token, copy + argmax %.1f us/token\n", t_fwd / n_tokens, t_host / n_tokens);
     clock_gettime(CLOCK_MONOTONIC, &t1);
     if (seconds) *seconds = (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9;
     return Q3_OK;

@@ -17,7 +17,7 @@ _DIST_DIR = os.path.dirname(_PKG_DIR)
 # every symbol include/qwen3_hip.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = [
     "q3_create", "q3_get_config", "q3_forward", "q3_destroy", "q3_last_error", "q3_forward_argmax",
-    "q3_generate_greedy", "q3_host_generate", "q3_prefill", "q3_reset_kv", "q3_read_state", "q3_batch_init", "q3_forward_batch",
+    "q3_generate_greedy", "q3_host_generate", "q3_host_sample_argmax", "q3_prefill", "q3_reset_kv", "q3_read_state", "q3_batch_init", "q3_forward_batch",
     "q3_generate_greedy_batch", "q3_batch_reset_kv", "q3_batch_read_state", "q3_prefill_batched", "q3_batch_sampler_set", "q3_sampler_set", "q3_sampler_get_rng", "q3_forward_sample", "q3_generate_sampled", "q3_profile", "q3_profile_name", "q3_parse_header",
     "q3_abi_version", "q3_build_id", "q3_op_quantize", "q3_op_dequantize", "q3_op_matmul", "q3_op_rmsnorm", "q3_op_softmax",
     "q3_op_swiglu", "q3_op_expf", "q3_op_attention", "q3_op_argmax", "q3_op_sample",
@@ -100,6 +100,8 @@ def load_library() -> C.CDLL:
     L.q3_forward_argmax.argtypes = [C.c_void_p, sz, sz, C.POINTER(C.c_int32)]
     L.q3_generate_greedy.argtypes = [C.c_void_p, sz, sz, sz, C.POINTER(C.c_int32)]
     L.q3_host_generate.argtypes = [C.c_void_p, sz, sz, sz, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    L.q3_host_sample_argmax.argtypes = [fp, sz, fp]
+    L.q3_host_sample_argmax.restype = sz
     L.q3_prefill.argtypes = [C.c_void_p, C.POINTER(C.c_int32), sz, sz, C.POINTER(C.c_int32)]
     L.q3_prefill_batched.argtypes = [C.c_void_p, C.POINTER(C.c_int32), sz, sz, C.POINTER(C.c_int32)]
     L.q3_sampler_set.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_uint64]

@@ -227,3 +227,41 @@ def test_bench_under_torchrun_two_ranks_stub_engine():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 6 and "_tokens" not in d
+
+
+def test_host_sample_argmax_last_maximum_under_total_order(q3):
+    """q3_host_sample_argmax (the host half of q3_host_generate: logits.to_vec() + Sampler::sample_argmax, sampler.rs:57-59):
+    index of the LAST maximum under f32::total_cmp, copy bit-identical -- ties, -0.0 < +0.0, NaNs (positive NaN above +inf,
+    negative NaN below -inf), lengths that are not a multiple of the vector width, aligned and unaligned destinations."""
+    import ctypes as C
+    import numpy as np
+    lib = q3.load_library()
+    fp = C.POINTER(C.c_float)
+
+    def total_key(a):
+        b = a.view(np.int32).astype(np.int64)
+        return np.where(b < 0, b ^ 0x7fffffff, b)
+
+    rng = np.random.default_rng(11)
+    cases = []
+    for n in (1, 7, 8, 9, 63, 1000, 151936):
+        a = rng.standard_normal(n).astype(np.float32)
+        cases.append(a)
+        t = a.copy(); t[rng.integers(0, n, 3)] = t.max()                  # ties: the last one wins
+        cases.append(t)
+    cases.append(np.array([0.0, -0.0, 0.0, -0.0], dtype=np.float32))     # +0.0 is the maximum, last occurrence index 2
+    cases.append(np.array([-0.0, -0.0], dtype=np.float32))
+    cases.append(np.array([1.0, np.inf, np.nan, 2.0, np.nan, -np.nan], dtype=np.float32))
+    cases.append(np.array([-np.inf, -1e30, -np.inf], dtype=np.float32))
+    for a in cases:
+        a = np.ascontiguousarray(a)
+        k = total_key(a)
+        want = int(np.nonzero(k == k.max())[0][-1])
+        for off in (0, 1):                                                 # aligned / unaligned destination
+            store = np.zeros(a.size + 16, dtype=np.float32)
+            base = (-store.ctypes.data // 4) % 8                           # first 32-byte aligned element
+            dst = store[base + off: base + off + a.size]
+            got = lib.q3_host_sample_argmax(a.ctypes.data_as(fp), a.size, dst.ctypes.data_as(fp))
+            assert got == want, (a[:8], got, want)
+            assert np.array_equal(dst.view(np.int32), a.view(np.int32))
+        assert lib.q3_host_sample_argmax(a.ctypes.data_as(fp), a.size, None) == want
