@@ -644,6 +644,174 @@ __global__ __launch_bounds__(kPgThreads) void k_pgemm(const BGemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Dense prefill matmul, round 4: workgroup tile staged in LDS (k_pgemm2).
+// k_pgemm gives every WAVE its own RT x PT output tiles and lets it pull its own fragments: 1 KiB through the CU's L1 path
+// per MFMA (1.3 GB per W1|W3 pass, r03), the matrix cores 9.8 % busy.  Here a workgroup of 8 waves owns 4 row tiles x 8
+// position tiles (64 rows x 128 positions); per quantization group its 4 weight fragments, 8 activation fragments and their
+// scales (12.75 KiB) are fetched ONCE by the workgroup (each wave requests one or two KiB, a register ring 4 groups ahead),
+// committed to one of two LDS slots, and read back by the waves: wave (wr, wp) computes row tiles {2wr, 2wr+1} x position
+// tiles {2wp, 2wp+1} -- 4 MFMAs per group from 4 KiB of ds_read_b128 -- and keeps the four accumulator tiles in its lanes:
+// acc += ((f32)idot * ws) * xs, g ascending from -0.0 (tensor.rs:53-60), the same operations in the same order as every other
+// matmul of this library.  Global traffic per MFMA drops from 1 KiB to 0.4 KiB (weights: 128 B), one barrier per group.
+// ------------------------------------------------------------------------------------------------
+constexpr int kP2Waves = 8, kP2Threads = 512, kP2RT = 4, kP2PT = 8, kP2D = 4;
+constexpr int kP2SlotBytes = (kP2RT + kP2PT) * 1024 + (kP2RT + kP2PT) * 64;      // fragments + scales of one group
+__host__ __device__ inline size_t pgemm2_smem_bytes() { return 2 * (size_t)kP2SlotBytes; }
+
+template <int EPI>
+__global__ __launch_bounds__(kP2Threads, 4) void k_pgemm2(const BGemmArgs a) {
+    constexpr int D = kP2D;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, s = lane & 15;
+    const int wr = wave >> 2, wp = wave & 3;                     // this wave's row-tile pair / position-tile pair inside the workgroup tile
+    const int ng = a.ng;
+    const int nptiles = (a.n_streams + 15) >> 4;
+    const int npb = (nptiles + kP2PT - 1) / kP2PT;               // position blocks
+    const int nrb = a.ntiles / kP2RT;                            // row blocks (host: ntiles % 4 == 0)
+    const size_t tile_v4 = (size_t)ng * 64;
+    // LDS slot: [4 A frags][8 B frags] v4i x 64, then [4][16] ws, [8][16] xs floats
+    auto slot_frag = [&](int sl) { return (v4i*)(smem_raw + (size_t)sl * kP2SlotBytes); };
+    auto slot_sc = [&](int sl) { return (float*)(smem_raw + (size_t)sl * kP2SlotBytes + (kP2RT + kP2PT) * 1024); };
+    for (int blk = blockIdx.x; blk < nrb * npb; blk += gridDim.x) {
+        const int rb = blk / npb, pb = blk - rb * npb;           // the position blocks of a row block run on neighbouring workgroups
+        // ---- loader roles (wave-uniform): every wave fetches the activation fragment of position tile `wave`; waves 0..3 also
+        // the weight fragment of row tile `wave`; wave 4 / 5 the position scales of tiles 0-3 / 4-7, wave 6 the row scales
+        const int ptile = min(pb * kP2PT + wave, nptiles - 1);   // (tiles past the block re-read the last one; never stored)
+        const v4i* bsrc = (const v4i*)a.xq + (size_t)ptile * tile_v4 + lane;
+        const v4i* asrc = (const v4i*)a.wq + (size_t)(rb * kP2RT + (wave & 3)) * tile_v4 + lane;
+        const float* ssrc;                                       // one scale dword per lane and group for the scale loaders
+        if (wave == 6) ssrc = a.ws + (size_t)(rb * kP2RT + (lane >> 4)) * ng * 16 + (lane & 15);
+        else ssrc = a.xs + (size_t)min(pb * kP2PT + (wave & 1) * 4 + (lane >> 4), nptiles - 1) * ng * 16 + (lane & 15);
+        const bool lda = wave < 4, lds_ = wave >= 4 && wave <= 6;
+        v4i rb_[D], ra_[D];
+        float rs_[D];
+        auto issue = [&](int sl, int g) {                        // group g -> register slot sl
+            const int gg = min(g, ng - 1);
+            rb_[sl] = bsrc[(size_t)gg * 64];
+            if (lda) ra_[sl] = asrc[(size_t)gg * 64];
+            if (lds_) rs_[sl] = ssrc[(size_t)gg * 16];
+        };
+        auto commit = [&](int sl, int ls) {                      // register slot sl -> LDS slot ls
+            v4i* f = slot_frag(ls);
+            f[(kP2RT + wave) * 64 + lane] = rb_[sl];
+            if (lda) f[wave * 64 + lane] = ra_[sl];
+            if (lds_) {
+                float* sc = slot_sc(ls);
+                if (wave == 6) sc[lane] = rs_[sl];               // ws [4][16]
+                else sc[kP2RT * 16 + (wave & 1) * 64 + lane] = rs_[sl];      // xs [8][16]
+            }
+        };
+        v4f acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = (v4f){-0.0f, -0.0f, -0.0f, -0.0f};      // Iterator::sum::<f32>() identity
+        // (no software pipeline inside a wave: at 4 waves per SIMD the other waves' MFMAs cover this wave's convert / scale / add
+        // chain, and a second set of MFMA results would push the kernel past 128 VGPRs, i.e. to one workgroup per CU)
+        v4i cc[2][2];
+        v4f wsc[2];
+        float xsc[2];
+        auto mfma_group = [&](int ls, v4i (&c)[2][2], v4f (&w)[2], float (&x)[2]) {    // MFMAs of the group in LDS slot ls -> c; its scales -> w, x
+            const v4i* f = slot_frag(ls);
+            const float* sc = slot_sc(ls);
+            v4i fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = f[(2 * wr + i) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = f[(kP2RT + 2 * wp + j) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) w[i] = *(const v4f*)(sc + (2 * wr + i) * 16 + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) x[j] = sc[kP2RT * 16 + (2 * wp + j) * 16 + s];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    c[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], (v4i){0, 0, 0, 0}, 0, 0, 0);
+        };
+        auto math_group = [&](const v4i (&cg)[2][2], const v4f (&w)[2], const float (&x)[2]) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const v4i c = cg[i][j];
+                    // tensor.rs:59  ((dot as f32) * ws) * xs, then the g-ascending add; pairs (rows 4q, 4q+1), (4q+2, 4q+3)
+                    pk2 t01 = (pk2){(float)c.x, (float)c.y} * (pk2){w[i].x, w[i].y};
+                    pk2 t23 = (pk2){(float)c.z, (float)c.w} * (pk2){w[i].z, w[i].w};
+                    asm("" : "+v"(t01)); asm("" : "+v"(t23));
+                    pk2 xb = (pk2){x[j], x[j]};
+                    asm("" : "+v"(xb));
+                    t01 = t01 * xb; t23 = t23 * xb;
+                    asm("" : "+v"(t01)); asm("" : "+v"(t23));
+                    v4f& ac = acc[i][j];
+                    pk2 a01 = (pk2){ac.x, ac.y} + t01, a23 = (pk2){ac.z, ac.w} + t23;
+                    asm("" : "+v"(a01)); asm("" : "+v"(a23));
+                    ac.x = a01.x; ac.y = a01.y; ac.z = a23.x; ac.w = a23.y;
+                }
+        };
+#pragma unroll
+        for (int d = 0; d < D; ++d) issue(d, d);
+        commit(0, 0);
+        issue(0, D);
+        __syncthreads();
+        // ---- pipeline.  Register slot of group x is x % D, LDS slot x % 2.  Stage g: the MFMAs and the convert / scale / add chain
+        // of group g (LDS slot g % 2); meanwhile group g + 1 (requested D - 1 stages ago) goes to the other LDS slot and group
+        // g + D is requested into the register slot it leaves; one barrier per group.
+        for (int g0 = 0; g0 < ng; g0 += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const int g = g0 + u;
+                commit((u + 1) % D, (u + 1) & 1);                // group g + 1 -> the other LDS slot (past the row: a re-read group)
+                issue((u + 1) % D, g + 1 + D);
+                mfma_group(u & 1, cc, wsc, xsc);
+                math_group(cc, wsc, xsc);
+                __syncthreads();                                 // group g + 1 visible; slot g % 2 free for group g + 2
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();                                         // the next block's prologue overwrites slot 0
+        // ---- epilogue: lane (s, q) owns out[position (pb*8 + 2wp + j)*16 + s][rows 4q .. 4q+3 of row tile rb*4 + 2wr + i]
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ptj = pb * kP2PT + 2 * wp + j;
+            const int sb = ptj * 16 + s;
+            if (ptj >= nptiles || sb >= a.n_streams) continue;
+            if constexpr (EPI == EPI_SWIGLU) {
+                // packed tiles alternate w1 | w3 of the same 16 hidden units            layers.rs:468-475
+                v4f o;
+                const v4f g1 = acc[0][j], up = acc[1][j];
+                { const float den = 1.0f + q3_expf(-g1.x); o.x = (g1.x * (1.0f / den)) * up.x; }
+                { const float den = 1.0f + q3_expf(-g1.y); o.y = (g1.y * (1.0f / den)) * up.y; }
+                { const float den = 1.0f + q3_expf(-g1.z); o.z = (g1.z * (1.0f / den)) * up.z; }
+                { const float den = 1.0f + q3_expf(-g1.w); o.w = (g1.w * (1.0f / den)) * up.w; }
+                *(v4f*)(a.out0 + (size_t)sb * a.out0_stride + (size_t)(rb * (kP2RT / 2) + wr) * 16 + 4 * q) = o;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int r0 = (rb * kP2RT + 2 * wr + i) * 16 + 4 * q;
+                    const v4f o = acc[i][j];
+                    if constexpr (EPI == EPI_QKV) {
+                        float* dst;
+                        if (r0 < a.rows0) dst = a.out0 + (size_t)sb * a.out0_stride + r0;
+                        else if (r0 < a.rows0 + a.rows1) dst = a.out1 + (size_t)sb * a.out1_stride + (r0 - a.rows0);
+                        else dst = a.out2 + (size_t)sb * a.out2_stride + (size_t)a.st[sb].pos * a.pos_stride + (r0 - a.rows0 - a.rows1);
+                        *(v4f*)dst = o;
+                    } else if constexpr (EPI == EPI_RESID) {
+                        v4f* dst = (v4f*)(a.out0 + (size_t)sb * a.out0_stride + r0);
+                        v4f x = *dst;
+                        x.x = x.x + o.x; x.y = x.y + o.y; x.z = x.z + o.z; x.w = x.w + o.w;      // layers.rs:249-259
+                        *dst = x;
+                    } else {
+                        *(v4f*)(a.out0 + (size_t)sb * a.out0_stride + r0) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Batched decode matmul, round 4: in-lane accumulation at 16-32 columns (k_dgemm).
 // k_bgemm splits K over the 8 waves of a workgroup and pays, per phase of 16-32 groups, a 64 KiB LDS term tile, two
 // barriers and a 16-32-term dependent fold behind LDS reads: with the weight loads compiled out its launches kept 70 % of

@@ -72,8 +72,12 @@ const GemvCfg kGemvCfgs[] = {
     // wave-0 block loads go through LDS; same-process A/B of the three 0.6B changes below: 1,552-1,567 -> 1,582-1,599 tok/s)
     Q3_CFG_NORM_QKV(1024, 512, 2, 2, 1, 0), Q3_CFG_NORM_QKV(1024, 1024, 1, 1, 1, 0), Q3_CFG_NORM_QKV(1024, 1024, 4, 1, 1, 0),
     Q3_CFG_NORM_QKV(1024, 256, 4, 2, 1, 0),
+    // (r04 sweep, 4B: 12 waves x 2 rows = 6,144 rows exactly, 6.18 vs 6.56 us; the same form at 4096 is slower, 8.33 vs 7.94 us)
+    Q3_CFG_NORM_QKV(2560, 768, 4, 2, 3, 0),
     Q3_CFG_NORM_QKV(2560, 1024, 4, 1, 3, 0), Q3_CFG_NORM_QKV(2560, 1024, 4, 1, 3, 1), Q3_CFG_NORM_QKV(2560, 1024, 4, 2, 3, 0),
     Q3_CFG_NORM_QKV(4096, 1024, 4, 1, 4, 0), Q3_CFG_NORM_QKV(4096, 1024, 4, 1, 4, 1), Q3_CFG_NORM_QKV(4096, 1024, 4, 2, 4, 0),
+    // (r04) 12-wave workgroups: 6,144 rows = 3,072 waves x 2 rows, every byte of the launch requested at kernel entry
+    Q3_CFG_NORM_QKV(4096, 768, 4, 2, 4, 0),
     // --- W1|W3 + SwiGLU
     Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 512, 2, 4, 1, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 1024, 1, 2, 1, 0),
     Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 1024, 4, 2, 1, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 256, 4, 4, 1, 0),
@@ -81,15 +85,18 @@ const GemvCfg kGemvCfgs[] = {
     Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 512, 4, 2, 3, 0),
     Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 1024, 4, 2, 4, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 512, 4, 2, 4, 1),
     Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 512, 4, 2, 4, 0),
+    // (r04: a 12-wave PF = 1 form still spills 92 B at 4096 and ran at 30.4 us; 2560: 16.5 vs 12.6 us -- not kept)
     // --- Wo behind the short-context attention kernel (xb arrives quantized): register-direct activation
     Q3_CFG(PRO_PREQR, EPI_RESID, 2048, 256, 4, 1, 2, 0), Q3_CFG(PRO_PREQR, EPI_RESID, 2048, 512, 4, 1, 2, 0),
     Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 256, 4, 1, 4, 0), Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 256, 4, 2, 4, 0),
-    Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 512, 4, 1, 4, 0),
+    Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 512, 4, 1, 4, 0), Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 1024, 4, 1, 4, 0),
     // --- quantize + W2 (and Wo of the long-context plan)
     Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 256, 4, 1, 3, 0), Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 512, 4, 1, 3, 0),
     Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 1024, 4, 1, 3, 0),
     Q3_CFG(PRO_QUANT, EPI_RESID, 9728, 1024, 4, 1, 2, 1), Q3_CFG(PRO_QUANT, EPI_RESID, 9728, 512, 4, 1, 2, 1),
     Q3_CFG(PRO_QUANT, EPI_RESID, 12288, 1024, 4, 1, 4, 1), Q3_CFG(PRO_QUANT, EPI_RESID, 12288, 512, 4, 1, 4, 1),
+    // (r04: the whole 12 KiB row of a wave requested before the prologue, two 6 KiB tiles: 13.3 vs 11.8 us; 9728 as 2 x 5 KiB: 9.2
+    // vs 8.3 us -- request depth at entry is not what these launches wait for)
     Q3_CFG(PRO_QUANT, EPI_RESID, 2048, 512, 4, 1, 2, 0), Q3_CFG(PRO_QUANT, EPI_RESID, 2048, 256, 4, 1, 2, 0),
     Q3_CFG(PRO_QUANT, EPI_RESID, 4096, 1024, 4, 1, 4, 0), Q3_CFG(PRO_QUANT, EPI_RESID, 4096, 512, 4, 1, 4, 0),
     // --- final RMSNorm + classifier (streaming: two tiles requested before the prologue)
