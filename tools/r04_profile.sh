@@ -1,7 +1,7 @@
 #!/bin/bash
-# round-3 rocprofv3 evidence: kernel-trace stats and PMC passes in SEPARATE runs; summaries land in gpurun_out/<dir>/ and are
-# copied into profiles/r03_* by hand.  Every profiled program is a single process that owns the GPU itself.
-out=gpurun_out/${1:-prof3}; mkdir -p $out; export TMPDIR=/tmp
+# round-4 rocprofv3 evidence: kernel-trace stats and PMC passes in SEPARATE runs; summaries land in gpurun_out/<dir>/ and are
+# copied into profiles/r04_* by hand.  Every profiled program is a single process that owns the GPU itself.
+out=gpurun_out/${1:-prof4}; mkdir -p $out; export TMPDIR=/tmp
 what=${2:-all}
 PY=python3
 $PY - <<'PYEOF'
