@@ -613,6 +613,41 @@ def test_batched_decode_8b_layer_dims_vs_forward_and_oracle(q3, oracle, form, mo
             tok = oracle.sample_argmax(lg)
 
 
+@pytest.mark.parametrize("form", [0, 1, 2, 6])
+def test_batched_decode_4b_layer_dims_vs_forward(q3, form, monkeypatch):
+    """The 4B matrix shapes on the batched path: row lengths 2560 / 9728 are 40 / 152 quantization groups -- not a multiple of
+    16, so k_dgemm runs its 8-group ring (and k_bgemm ragged phases) -- 20 streams (a ragged second stream tile), 6 steps: logits
+    of four streams bit-identical to q3_forward.  Forms as in _DGEMM_FORMS (default, every family in-lane at both depths, k_bgemm)."""
+    for k, v in _DGEMM_FORMS[form].items():
+        monkeypatch.setenv(k, v)
+    ck = q3.checkpoint
+    name = "qwen3-4b-dims-l2"
+    shape = ck.SHAPES[name]
+    path = os.path.join(os.environ.get("Q3_CKPT_DIR", "/tmp"), f"q3_{name}.bin")
+    ck.ensure_synthetic_checkpoint(path, shape, seed=1235)
+    n_streams, steps = 20, 6
+    rng = np.random.default_rng(6)
+    toks0 = [int(t) for t in rng.integers(0, shape.vocab_size, n_streams)]
+    pos0 = [int(p) for p in rng.integers(0, 9, n_streams)]
+    with q3.TransformerBuilder(path).with_ctx_length(64).build() as t:
+        ref = {}
+        for i in (0, 7, 16, 19):
+            t.reset_kv()
+            tok, ll = toks0[i], []
+            for k in range(steps):
+                lg = np.array(t.forward(tok, pos0[i] + k), copy=True)
+                ll.append(lg)
+                tok = q3.sample_argmax(lg)
+            ref[i] = ll
+        t.batch_init(n_streams, 64)
+        toks = list(toks0)
+        for k in range(steps):
+            lg, am = t.forward_batch(toks, [p + k for p in pos0])
+            for i in ref:
+                assert_biteq(lg[i], ref[i][k], f"stream {i} step {k}")
+            toks = am
+
+
 def test_full_size_8b_batch32_streams_equal_single_stream(q3, oracle):
     """BASELINE config 4 at FULL size (Qwen3-8B shape, 36 layers, vocab 151936, untied): 32 concurrent greedy streams x
     16 steps; two of the streams re-run single-stream on the same engine must give the same tokens (the size-independent
