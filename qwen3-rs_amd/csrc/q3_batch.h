@@ -654,87 +654,99 @@ __global__ __launch_bounds__(kPgThreads) void k_pgemm(const BGemmArgs a) {
 // acc += ((f32)idot * ws) * xs, g ascending from -0.0 (tensor.rs:53-60), the same operations in the same order as every other
 // matmul of this library.  Global traffic per MFMA drops from 1 KiB to 0.4 KiB (weights: 128 B), one barrier per group.
 // ------------------------------------------------------------------------------------------------
-constexpr int kP2Waves = 8, kP2Threads = 512, kP2RT = 4, kP2PT = 8, kP2D = 4;
-constexpr int kP2SlotBytes = (kP2RT + kP2PT) * 1024 + (kP2RT + kP2PT) * 64;      // fragments + scales of one group
-__host__ __device__ inline size_t pgemm2_smem_bytes() { return 2 * (size_t)kP2SlotBytes; }
+// PTW = 8 position tiles per workgroup (wave: 2 x 2 tiles) or 4 (wave: 2 x 1): the smaller tile doubles the number of workgroup
+// tiles -- W1|W3 of the 4B shape has 608 tiles of 4 x 8 on 512 resident workgroup slots (two full rounds for 1.19 rounds of work),
+// 1,216 of 4 x 4 run as three rounds of half the length; QKV goes from 192 tiles (fewer than CUs) to 384.
+constexpr int kP2Waves = 8, kP2Threads = 512, kP2RT = 4, kP2D = 4;
+__host__ __device__ inline size_t pgemm2_slot_bytes(int ptw, int rtw) { return (size_t)(rtw + ptw) * 1024 + (size_t)(rtw + ptw) * 64; }     // fragments + scales of one group
+__host__ __device__ inline size_t pgemm2_smem_bytes(int ptw, int rtw = 4) { return (ptw == 4 ? 3 : 2) * pgemm2_slot_bytes(ptw, rtw); }
 
-template <int EPI>
+template <int EPI, int PTW, int RTW = 4>
 __global__ __launch_bounds__(kP2Threads, 4) void k_pgemm2(const BGemmArgs a) {
     constexpr int D = kP2D;
+    constexpr int NF = RTW + PTW;                                // fragments per group: [A0..A(RTW-1)][B0..B(PTW-1)]
+    constexpr int NRW = RTW / 2;                                 // row tiles per wave (SwiGLU: the w1 and the w3 tile -> RTW = 4)
+    static_assert(RTW == 4 || (RTW == 2 && EPI != EPI_SWIGLU), "2-row-tile workgroups: one row tile per wave");
+    constexpr int NPW = PTW / 4;                                 // position tiles per wave
+    constexpr size_t kSlot = (size_t)NF * 1024 + (size_t)NF * 64;
+    static_assert(PTW == 4 || PTW == 8, "workgroup tile: 4 row tiles x 4 or 8 position tiles");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, s = lane & 15;
-    const int wr = wave >> 2, wp = wave & 3;                     // this wave's row-tile pair / position-tile pair inside the workgroup tile
+    const int wr = wave >> 2, wp = wave & 3;                     // this wave's row-tile pair / position-tile slot inside the workgroup tile
     const int ng = a.ng;
     const int nptiles = (a.n_streams + 15) >> 4;
-    const int npb = (nptiles + kP2PT - 1) / kP2PT;               // position blocks
-    const int nrb = a.ntiles / kP2RT;                            // row blocks (host: ntiles % 4 == 0)
+    const int npb = (nptiles + PTW - 1) / PTW;                   // position blocks
+    const int nrb = a.ntiles / RTW;                            // row blocks (host: ntiles % 4 == 0)
     const size_t tile_v4 = (size_t)ng * 64;
-    // LDS slot: [4 A frags][8 B frags] v4i x 64, then [4][16] ws, [8][16] xs floats
-    auto slot_frag = [&](int sl) { return (v4i*)(smem_raw + (size_t)sl * kP2SlotBytes); };
-    auto slot_sc = [&](int sl) { return (float*)(smem_raw + (size_t)sl * kP2SlotBytes + (kP2RT + kP2PT) * 1024); };
+    // LDS slot: [NF fragments] v4i x 64, then [4][16] ws, [PTW][16] xs floats
+    auto slot_frag = [&](int sl) { return (v4i*)(smem_raw + (size_t)sl * kSlot); };
+    auto slot_sc = [&](int sl) { return (float*)(smem_raw + (size_t)sl * kSlot + (size_t)NF * 1024); };
     for (int blk = blockIdx.x; blk < nrb * npb; blk += gridDim.x) {
         const int rb = blk / npb, pb = blk - rb * npb;           // the position blocks of a row block run on neighbouring workgroups
-        // ---- loader roles (wave-uniform): every wave fetches the activation fragment of position tile `wave`; waves 0..3 also
-        // the weight fragment of row tile `wave`; wave 4 / 5 the position scales of tiles 0-3 / 4-7, wave 6 the row scales
-        const int ptile = min(pb * kP2PT + wave, nptiles - 1);   // (tiles past the block re-read the last one; never stored)
-        const v4i* bsrc = (const v4i*)a.xq + (size_t)ptile * tile_v4 + lane;
-        const v4i* asrc = (const v4i*)a.wq + (size_t)(rb * kP2RT + (wave & 3)) * tile_v4 + lane;
-        const float* ssrc;                                       // one scale dword per lane and group for the scale loaders
-        if (wave == 6) ssrc = a.ws + (size_t)(rb * kP2RT + (lane >> 4)) * ng * 16 + (lane & 15);
-        else ssrc = a.xs + (size_t)min(pb * kP2PT + (wave & 1) * 4 + (lane >> 4), nptiles - 1) * ng * 16 + (lane & 15);
-        const bool lda = wave < 4, lds_ = wave >= 4 && wave <= 6;
-        v4i rb_[D], ra_[D];
+        // ---- loader roles (wave-uniform).  Fragment f of the group goes to wave f % 8 (waves 0..NF-9 carry two); the scales:
+        // wave 7 the row scales (4 tiles x 16 lanes), wave 6 / 5 the position scales of tiles 0-3 / 4-7
+        auto frag_src = [&](int f) -> const v4i* {
+            if (f < RTW) return (const v4i*)a.wq + (size_t)(rb * RTW + f) * tile_v4 + lane;
+            return (const v4i*)a.xq + (size_t)min(pb * PTW + (f - RTW), nptiles - 1) * tile_v4 + lane;      // (tiles past the block re-read the last one)
+        };
+        const bool one = wave < NF;                              // (2 x 4 tiles: six fragments, waves 6 and 7 only carry scales)
+        const v4i* src0 = frag_src(one ? wave : 0);
+        const bool two = wave + 8 < NF;
+        const v4i* src1 = frag_src(two ? wave + 8 : wave);
+        const bool ld_ws = wave == 7, ld_xs = wave == 6 || (PTW == 8 && wave == 5);
+        const float* ssrc = a.ws;                                // one scale dword per lane and group for the scale loaders
+        if (ld_ws) ssrc = a.ws + (size_t)(rb * RTW + min(lane >> 4, RTW - 1)) * ng * 16 + (lane & 15);
+        if (ld_xs) ssrc = a.xs + (size_t)min(pb * PTW + (wave == 5 ? 4 : 0) + (lane >> 4), nptiles - 1) * ng * 16 + (lane & 15);
+        v4i r0_[D], r1_[D];
         float rs_[D];
         auto issue = [&](int sl, int g) {                        // group g -> register slot sl
             const int gg = min(g, ng - 1);
-            rb_[sl] = bsrc[(size_t)gg * 64];
-            if (lda) ra_[sl] = asrc[(size_t)gg * 64];
-            if (lds_) rs_[sl] = ssrc[(size_t)gg * 16];
+            r0_[sl] = src0[(size_t)gg * 64];                     // (unconditional: a wave without a fragment re-reads fragment 0 and drops it --
+            if (two) r1_[sl] = src1[(size_t)gg * 64];            //  a branch around the first request made hipcc give up its counted waits: 45 -> 76 us)
+            if (ld_ws || ld_xs) rs_[sl] = ssrc[(size_t)gg * 16];
         };
         auto commit = [&](int sl, int ls) {                      // register slot sl -> LDS slot ls
             v4i* f = slot_frag(ls);
-            f[(kP2RT + wave) * 64 + lane] = rb_[sl];
-            if (lda) f[wave * 64 + lane] = ra_[sl];
-            if (lds_) {
-                float* sc = slot_sc(ls);
-                if (wave == 6) sc[lane] = rs_[sl];               // ws [4][16]
-                else sc[kP2RT * 16 + (wave & 1) * 64 + lane] = rs_[sl];      // xs [8][16]
-            }
+            if (one) f[wave * 64 + lane] = r0_[sl];
+            if (two) f[(wave + 8) * 64 + lane] = r1_[sl];
+            float* sc = slot_sc(ls);
+            if (ld_ws && lane < RTW * 16) sc[lane] = rs_[sl];                            // ws [RTW][16]
+            if (ld_xs) sc[RTW * 16 + (wave == 5 ? 64 : 0) + lane] = rs_[sl];         // xs [PTW][16]
         };
-        v4f acc[2][2];
+        v4f acc[NRW][NPW];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NRW; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = (v4f){-0.0f, -0.0f, -0.0f, -0.0f};      // Iterator::sum::<f32>() identity
+            for (int j = 0; j < NPW; ++j) acc[i][j] = (v4f){-0.0f, -0.0f, -0.0f, -0.0f};    // Iterator::sum::<f32>() identity
         // (no software pipeline inside a wave: at 4 waves per SIMD the other waves' MFMAs cover this wave's convert / scale / add
         // chain, and a second set of MFMA results would push the kernel past 128 VGPRs, i.e. to one workgroup per CU)
-        v4i cc[2][2];
-        v4f wsc[2];
-        float xsc[2];
-        auto mfma_group = [&](int ls, v4i (&c)[2][2], v4f (&w)[2], float (&x)[2]) {    // MFMAs of the group in LDS slot ls -> c; its scales -> w, x
+        v4i cc[NRW][NPW];
+        v4f wsc[NRW];
+        float xsc[NPW];
+        auto mfma_group = [&](int ls, v4i (&c)[NRW][NPW], v4f (&w)[NRW], float (&x)[NPW]) {    // MFMAs of the group in LDS slot ls -> c; its scales -> w, x
             const v4i* f = slot_frag(ls);
             const float* sc = slot_sc(ls);
-            v4i fa[2], fb[2];
+            v4i fa[NRW], fb[NPW];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = f[(2 * wr + i) * 64 + lane];
+            for (int i = 0; i < NRW; ++i) fa[i] = f[(NRW * wr + i) * 64 + lane];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = f[(kP2RT + 2 * wp + j) * 64 + lane];
+            for (int j = 0; j < NPW; ++j) fb[j] = f[(RTW + NPW * wp + j) * 64 + lane];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) w[i] = *(const v4f*)(sc + (2 * wr + i) * 16 + 4 * q);
+            for (int i = 0; i < NRW; ++i) w[i] = *(const v4f*)(sc + (NRW * wr + i) * 16 + 4 * q);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) x[j] = sc[kP2RT * 16 + (2 * wp + j) * 16 + s];
+            for (int j = 0; j < NPW; ++j) x[j] = sc[RTW * 16 + (NPW * wp + j) * 16 + s];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NRW; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NPW; ++j)
                     c[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], (v4i){0, 0, 0, 0}, 0, 0, 0);
         };
-        auto math_group = [&](const v4i (&cg)[2][2], const v4f (&w)[2], const float (&x)[2]) {
+        auto math_group = [&](const v4i (&cg)[NRW][NPW], const v4f (&w)[NRW], const float (&x)[NPW]) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NRW; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NPW; ++j) {
                     const v4i c = cg[i][j];
                     // tensor.rs:59  ((dot as f32) * ws) * xs, then the g-ascending add; pairs (rows 4q, 4q+1), (4q+2, 4q+3)
                     pk2 t01 = (pk2){(float)c.x, (float)c.y} * (pk2){w[i].x, w[i].y};
@@ -750,31 +762,85 @@ __global__ __launch_bounds__(kP2Threads, 4) void k_pgemm2(const BGemmArgs a) {
                     ac.x = a01.x; ac.y = a01.y; ac.z = a23.x; ac.w = a23.y;
                 }
         };
+        if constexpr (PTW == 8) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) issue(d, d);
-        commit(0, 0);
-        issue(0, D);
-        __syncthreads();
-        // ---- pipeline.  Register slot of group x is x % D, LDS slot x % 2.  Stage g: the MFMAs and the convert / scale / add chain
-        // of group g (LDS slot g % 2); meanwhile group g + 1 (requested D - 1 stages ago) goes to the other LDS slot and group
-        // g + D is requested into the register slot it leaves; one barrier per group.
-        for (int g0 = 0; g0 < ng; g0 += D) {
+            for (int d = 0; d < D; ++d) issue(d, d);
+            commit(0, 0);
+            issue(0, D);
+            __syncthreads();
+            // ---- pipeline.  Register slot of group x is x % D, LDS slot x % 2.  Stage g: the MFMAs and the convert / scale / add
+            // chain of group g (LDS slot g % 2); meanwhile group g + 1 (requested D - 1 stages ago) goes to the other LDS slot and
+            // group g + D is requested into the register slot it leaves; one barrier per group.
+            for (int g0 = 0; g0 < ng; g0 += D) {
 #pragma unroll
-            for (int u = 0; u < D; ++u) {
-                const int g = g0 + u;
-                commit((u + 1) % D, (u + 1) & 1);                // group g + 1 -> the other LDS slot (past the row: a re-read group)
-                issue((u + 1) % D, g + 1 + D);
-                mfma_group(u & 1, cc, wsc, xsc);
-                math_group(cc, wsc, xsc);
-                __syncthreads();                                 // group g + 1 visible; slot g % 2 free for group g + 2
-                __builtin_amdgcn_sched_barrier(0);
+                for (int u = 0; u < D; ++u) {
+                    const int g = g0 + u;
+                    commit((u + 1) % D, (u + 1) & 1);            // group g + 1 -> the other LDS slot (past the row: a re-read group)
+                    issue((u + 1) % D, g + 1 + D);
+                    mfma_group(u & 1, cc, wsc, xsc);
+                    math_group(cc, wsc, xsc);
+                    __syncthreads();                             // group g + 1 visible; slot g % 2 free for group g + 2
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+            // ---- 4 x 4 tiles (78 VGPRs: room for a second fragment set): THREE LDS slots, the fragments of group g + 1 are read into
+            // registers while the MFMAs and the chain of group g run, so neither the LDS latency nor the barrier wait sits between a
+            // group's read and its MFMAs (a lone workgroup per CU -- Wo / W2 -- had nothing else to cover them: 33.7 us).  Stage g:
+            // commit group g + 2 -> slot (g + 2) % 3, request group g + 2 + D - 2, read group g + 1 (slot (g + 1) % 3, visible since
+            // the barrier of stage g - 1), compute group g from the registers read in stage g - 1, barrier.
+            static_assert((D & 1) == 0, "register-set parity is compile-time");
+            v4i fa2[2][NRW], fb2[2][NPW];                          // [parity][...]: fragments of the group computed in this / the next stage
+            v4f w2[2][NRW];
+            float x2[2][NPW];
+            auto read_group = [&](int ls, int par) {
+                const v4i* f = slot_frag(ls);
+                const float* sc = slot_sc(ls);
+#pragma unroll
+                for (int i = 0; i < NRW; ++i) fa2[par][i] = f[(NRW * wr + i) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < NPW; ++j) fb2[par][j] = f[(RTW + NPW * wp + j) * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < NRW; ++i) w2[par][i] = *(const v4f*)(sc + (NRW * wr + i) * 16 + 4 * q);
+#pragma unroll
+                for (int j = 0; j < NPW; ++j) x2[par][j] = sc[RTW * 16 + (NPW * wp + j) * 16 + s];
+            };
+            auto compute = [&](int par) {
+#pragma unroll
+                for (int i = 0; i < NRW; ++i)
+#pragma unroll
+                    for (int j = 0; j < NPW; ++j)
+                        cc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa2[par][i], fb2[par][j], (v4i){0, 0, 0, 0}, 0, 0, 0);
+                math_group(cc, w2[par], x2[par]);
+            };
+#pragma unroll
+            for (int d = 0; d < D; ++d) issue(d, d);
+            commit(0, 0);                                        // groups 0 and 1 -> LDS slots 0 and 1
+            commit(1, 1);
+            issue(0, D);
+            issue(1, D + 1);
+            __syncthreads();
+            read_group(0, 0);                                    // group 0 -> register set 0
+            int l1 = 1, l2 = 2;                                  // LDS slots of groups g + 1 and g + 2 (run-time: g % 3 does not divide the unroll)
+            for (int g0 = 0; g0 < ng; g0 += D) {
+#pragma unroll
+                for (int u = 0; u < D; ++u) {
+                    const int g = g0 + u;
+                    commit((u + 2) % D, l2);                     // group g + 2 (requested D - 2 stages ago)
+                    issue((u + 2) % D, g + 2 + D);
+                    read_group(l1, (u + 1) & 1);                 // group g + 1 (past the row: a re-read group, dropped)
+                    compute(u & 1);
+                    __syncthreads();                             // group g + 2 visible; slot g % 3 free for group g + 3
+                    l1 = l2;
+                    l2 = l2 == 2 ? 0 : l2 + 1;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
-        __syncthreads();                                         // the next block's prologue overwrites slot 0
-        // ---- epilogue: lane (s, q) owns out[position (pb*8 + 2wp + j)*16 + s][rows 4q .. 4q+3 of row tile rb*4 + 2wr + i]
+        // ---- epilogue: lane (s, q) owns out[position (pb*PTW + NPW*wp + j)*16 + s][rows 4q .. 4q+3 of row tile rb*4 + 2wr + i]
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int ptj = pb * kP2PT + 2 * wp + j;
+        for (int j = 0; j < NPW; ++j) {
+            const int ptj = pb * PTW + NPW * wp + j;
             const int sb = ptj * 16 + s;
             if (ptj >= nptiles || sb >= a.n_streams) continue;
             if constexpr (EPI == EPI_SWIGLU) {
@@ -785,11 +851,11 @@ __global__ __launch_bounds__(kP2Threads, 4) void k_pgemm2(const BGemmArgs a) {
                 { const float den = 1.0f + q3_expf(-g1.y); o.y = (g1.y * (1.0f / den)) * up.y; }
                 { const float den = 1.0f + q3_expf(-g1.z); o.z = (g1.z * (1.0f / den)) * up.z; }
                 { const float den = 1.0f + q3_expf(-g1.w); o.w = (g1.w * (1.0f / den)) * up.w; }
-                *(v4f*)(a.out0 + (size_t)sb * a.out0_stride + (size_t)(rb * (kP2RT / 2) + wr) * 16 + 4 * q) = o;
+                *(v4f*)(a.out0 + (size_t)sb * a.out0_stride + (size_t)(rb * (RTW / 2) + wr) * 16 + 4 * q) = o;
             } else {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int r0 = (rb * kP2RT + 2 * wr + i) * 16 + 4 * q;
+                for (int i = 0; i < NRW; ++i) {
+                    const int r0 = (rb * RTW + NRW * wr + i) * 16 + 4 * q;
                     const v4f o = acc[i][j];
                     if constexpr (EPI == EPI_QKV) {
                         float* dst;

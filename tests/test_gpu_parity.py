@@ -514,11 +514,14 @@ def test_batched_prefill_block_sizes_agree(q3, block, shape_name, tmp_path_facto
     """Q3_PREFILL_M picks the positions per weight pass: 32 = the batch-32 kernels (k_bgemm + LDS term tile), larger blocks
     the dense kernels (k_pgemm in-lane fold, k_attn_pf).  Every block size must give the cache rows and tokens of the
     sequential prompt loop (generation.rs:116-123) bit for bit, including a ragged last block and a non-zero start.
-    Negative block: the same size with the LDS-tiled matmul k_pgemm2 forced on every eligible matrix (Q3_PGEMM2=2; by
-    default only matrices with at least one workgroup tile per CU take it, which these small shapes do not have)."""
-    if block < 0:
-        monkeypatch.setenv("Q3_PGEMM2", "2")
-        block = -block
+    Blocks of 128 / 256 run the LDS-tiled matmul k_pgemm2 with 4 x 4 position-tile workgroups by default on these shapes;
+    negative block: the same size with its other forms -- -128: 2 row tiles per workgroup (Q3_PGEMM2_RT=2), -256: 4 x 8 tiles
+    (Q3_PGEMM2_PT=8); 48 positions (3 tiles) stay on k_pgemm."""
+    if block == -128:
+        monkeypatch.setenv("Q3_PGEMM2_RT", "2")
+    if block == -256:
+        monkeypatch.setenv("Q3_PGEMM2_PT", "8")
+    block = abs(block)
     ck = q3.checkpoint
     shape = ck.SHAPES[shape_name]
     path = str(tmp_path_factory.mktemp("preb") / "m.bin")
