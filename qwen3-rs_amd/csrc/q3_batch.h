@@ -661,6 +661,13 @@ constexpr int kP2Waves = 8, kP2Threads = 512, kP2RT = 4, kP2D = 4;
 __host__ __device__ inline size_t pgemm2_slot_bytes(int ptw, int rtw) { return (size_t)(rtw + ptw) * 1024 + (size_t)(rtw + ptw) * 64; }     // fragments + scales of one group
 __host__ __device__ inline size_t pgemm2_smem_bytes(int ptw, int rtw = 4) { return (ptw == 4 ? 3 : 2) * pgemm2_slot_bytes(ptw, rtw); }
 
+// developer ablation of k_pgemm2, compile-time only (-DQ3_PABLATE=bits; wrong results, time only): 1 no global requests in the
+// loop, 2 no convert / scale / add chain, 4 no MFMAs, 8 no barrier in the group loop, 16 no LDS commits
+#ifdef Q3_PABLATE
+#define Q3_PABL(bit) ((Q3_PABLATE & (bit)) != 0)
+#else
+#define Q3_PABL(bit) false
+#endif
 template <int EPI, int PTW, int RTW = 4>
 __global__ __launch_bounds__(kP2Threads, 4) void k_pgemm2(const BGemmArgs a) {
     constexpr int D = kP2D;
@@ -701,12 +708,14 @@ __global__ __launch_bounds__(kP2Threads, 4) void k_pgemm2(const BGemmArgs a) {
         v4i r0_[D], r1_[D];
         float rs_[D];
         auto issue = [&](int sl, int g) {                        // group g -> register slot sl
+            if (Q3_PABL(1) && g >= D + 2) return;
             const int gg = min(g, ng - 1);
             r0_[sl] = src0[(size_t)gg * 64];                     // (unconditional: a wave without a fragment re-reads fragment 0 and drops it --
             if (two) r1_[sl] = src1[(size_t)gg * 64];            //  a branch around the first request made hipcc give up its counted waits: 45 -> 76 us)
             if (ld_ws || ld_xs) rs_[sl] = ssrc[(size_t)gg * 16];
         };
         auto commit = [&](int sl, int ls) {                      // register slot sl -> LDS slot ls
+            if (Q3_PABL(16)) return;
             v4i* f = slot_frag(ls);
             if (one) f[wave * 64 + lane] = r0_[sl];
             if (two) f[(wave + 8) * 64 + lane] = r1_[sl];
@@ -748,6 +757,7 @@ __global__ __launch_bounds__(kP2Threads, 4) void k_pgemm2(const BGemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < NPW; ++j) {
                     const v4i c = cg[i][j];
+                    if (Q3_PABL(2)) { acc[i][j].x = __int_as_float(__float_as_int(acc[i][j].x) ^ c.x ^ c.y ^ c.z ^ c.w ^ __float_as_int(w[i].x) ^ __float_as_int(x[j])); continue; }
                     // tensor.rs:59  ((dot as f32) * ws) * xs, then the g-ascending add; pairs (rows 4q, 4q+1), (4q+2, 4q+3)
                     pk2 t01 = (pk2){(float)c.x, (float)c.y} * (pk2){w[i].x, w[i].y};
                     pk2 t23 = (pk2){(float)c.z, (float)c.w} * (pk2){w[i].z, w[i].w};
@@ -810,7 +820,7 @@ __global__ __launch_bounds__(kP2Threads, 4) void k_pgemm2(const BGemmArgs a) {
                 for (int i = 0; i < NRW; ++i)
 #pragma unroll
                     for (int j = 0; j < NPW; ++j)
-                        cc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa2[par][i], fb2[par][j], (v4i){0, 0, 0, 0}, 0, 0, 0);
+                        cc[i][j] = Q3_PABL(4) ? fa2[par][i] ^ fb2[par][j] : __builtin_amdgcn_mfma_i32_16x16x64_i8(fa2[par][i], fb2[par][j], (v4i){0, 0, 0, 0}, 0, 0, 0);
                 math_group(cc, w2[par], x2[par]);
             };
 #pragma unroll
@@ -830,7 +840,7 @@ __global__ __launch_bounds__(kP2Threads, 4) void k_pgemm2(const BGemmArgs a) {
                     issue((u + 2) % D, g + 2 + D);
                     read_group(l1, (u + 1) & 1);                 // group g + 1 (past the row: a re-read group, dropped)
                     compute(u & 1);
-                    __syncthreads();                             // group g + 2 visible; slot g % 3 free for group g + 3
+                    if (!Q3_PABL(8)) __syncthreads();            // group g + 2 visible; slot g % 3 free for group g + 3
                     l1 = l2;
                     l2 = l2 == 2 ? 0 : l2 + 1;
                     __builtin_amdgcn_sched_barrier(0);
@@ -874,6 +884,200 @@ __global__ __launch_bounds__(kP2Threads, 4) void k_pgemm2(const BGemmArgs a) {
                 }
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_pgemm3: k_pgemm2's workgroup tile with GS quantization groups per pipeline stage.
+// The ablation of k_pgemm2 (profiles/r04_prefill_ab.txt) showed a stage that is a serial chain of latencies -- barrier -> ds_read ->
+// MFMA -> convert / scale / add chain -> commit of the next group -> barrier, ~700 cycles for ~100 cycles of pipe work -- with
+// the arithmetic itself free (no-VALU and no-MFMA builds run at the same speed).  Here one barrier covers GS groups: a stage's
+// fragments and scales (GS x 8.5 KiB for 4 x 4 tiles) sit in one of two LDS slots, every wave requests its share of stage s + 2
+// into registers while stage s is computed, and commits stage s + 1 (requested two stages ago) after its own compute; inside a
+// stage the GS groups are independent until the ordered adds, so their LDS reads, MFMAs and multiply chains overlap.
+// Same accumulation order per (row, position): groups ascending, acc += ((f32)idot * ws) * xs from -0.0 (tensor.rs:53-60).
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t pgemm3_slot_bytes(int ptw, int rtw, int gs) { return (size_t)gs * ((size_t)(rtw + ptw) * 1024 + (size_t)(rtw + ptw) * 64); }
+__host__ __device__ inline size_t pgemm3_smem_bytes(int ptw, int rtw, int gs) { return 2 * pgemm3_slot_bytes(ptw, rtw, gs); }
+
+template <int EPI, int PTW, int RTW, int GS>
+__global__ __launch_bounds__(kP2Threads, 4) void k_pgemm3(const BGemmArgs a) {
+    constexpr int NF = RTW + PTW;                                // fragments per group: [A0..A(RTW-1)][B0..B(PTW-1)]
+    constexpr int NRW = RTW / 2, NPW = PTW / 4;                  // row / position tiles per wave
+    constexpr int NJ = GS * NF;                                  // fragment jobs (1 KiB each) per stage
+    constexpr int JW = (NJ + 7) / 8;                             // ... per wave
+    constexpr int NSC = GS * NF * 16;                            // scale floats per stage
+    constexpr int SW = (NSC + kP2Threads - 1) / kP2Threads;      // ... per thread (1)
+    constexpr size_t kSlot = (size_t)GS * ((size_t)NF * 1024 + (size_t)NF * 64);
+    static_assert(RTW == 4 || (RTW == 2 && EPI != EPI_SWIGLU), "2-row-tile workgroups: one row tile per wave");
+    static_assert(SW == 1, "one scale dword per thread and stage");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, s = lane & 15;
+    const int wr = wave >> 2, wp = wave & 3;
+    const int ng = a.ng;
+    const int nst = ng / GS;                                     // stages (host: ng % (2 GS) == 0)
+    const int nptiles = (a.n_streams + 15) >> 4;
+    const int npb = (nptiles + PTW - 1) / PTW;
+    const int nrb = a.ntiles / RTW;
+    const size_t tile_v4 = (size_t)ng * 64;
+    // LDS slot: [GS][NF] fragments (v4i x 64 each), then [GS][NF][16] scales (row tiles first, then position tiles)
+    auto slot_frag = [&](int sl) { return (v4i*)(smem_raw + (size_t)sl * kSlot); };
+    auto slot_sc = [&](int sl) { return (float*)(smem_raw + (size_t)sl * kSlot + (size_t)GS * NF * 1024); };
+    for (int blk = blockIdx.x; blk < nrb * npb; blk += gridDim.x) {
+        const int rb = blk / npb, pb = blk - rb * npb;
+        // ---- loader jobs of this wave: job j = wave + 8 i  ->  (group k = j / NF of the stage, fragment f = j % NF)
+        const v4i* jsrc[JW];
+        int jk[JW];
+#pragma unroll
+        for (int i = 0; i < JW; ++i) {
+            const int j = min(wave + 8 * i, NJ - 1);             // (a wave past the job list re-reads the last job and drops it)
+            const int k = j / NF, f = j - k * NF;
+            jk[i] = k;
+            // (wave-uniform bases: scalar registers; the lane offset is added at the request)
+            if (f < RTW) jsrc[i] = (const v4i*)a.wq + (size_t)(rb * RTW + f) * tile_v4;
+            else jsrc[i] = (const v4i*)a.xq + (size_t)min(pb * PTW + (f - RTW), nptiles - 1) * tile_v4;
+        }
+        // scale job of this thread: element e = tid of [GS][NF][16]
+        const int e_ = min(tid, NSC - 1);
+        const int ek = e_ / (NF * 16), er = e_ - ek * (NF * 16), et = er >> 4, ei = er & 15;
+        const float* ssrc = et < RTW ? a.ws + (size_t)(rb * RTW + et) * ng * 16 + ei
+                                     : a.xs + (size_t)min(pb * PTW + (et - RTW), nptiles - 1) * ng * 16 + ei;
+        v4i rj[2][JW];
+        float rsc[2];
+        auto issue = [&](int rs, int st) {                       // stage st -> register set rs (past the row: a re-read stage)
+            const int g0 = min(st, nst - 1) * GS;
+#pragma unroll
+            for (int i = 0; i < JW; ++i) rj[rs][i] = (jsrc[i] + (size_t)(g0 + jk[i]) * 64)[lane];
+            rsc[rs] = ssrc[(size_t)(g0 + ek) * 16];
+        };
+        auto commit = [&](int rs, int ls) {
+            v4i* f = slot_frag(ls);
+#pragma unroll
+            for (int i = 0; i < JW; ++i)
+                if (wave + 8 * i < NJ) f[(size_t)(wave + 8 * i) * 64 + lane] = rj[rs][i];
+            if (tid < NSC) slot_sc(ls)[tid] = rsc[rs];
+        };
+        v4f acc[NRW][NPW];
+#pragma unroll
+        for (int i = 0; i < NRW; ++i)
+#pragma unroll
+            for (int j = 0; j < NPW; ++j) acc[i][j] = (v4f){-0.0f, -0.0f, -0.0f, -0.0f};    // Iterator::sum::<f32>() identity
+        // a stage is computed HS groups at a time (their reads, MFMAs and multiply chains are independent and overlap; all GS at once
+        // needs ~155 VGPRs), the ordered adds of a sub-step follow its terms
+        constexpr int HS = (GS >= 2 && NPW == 1) ? 2 : 1;
+        auto compute = [&](int ls) {
+            const v4i* f = slot_frag(ls);
+            const float* sc = slot_sc(ls);
+#pragma unroll
+            for (int k0 = 0; k0 < GS; k0 += HS) {
+                v4i cc[HS][NRW][NPW];
+                v4f w[HS][NRW];
+                float x[HS][NPW];
+#pragma unroll
+                for (int h = 0; h < HS; ++h) {
+                    const int k = k0 + h;
+                    v4i fa[NRW], fb[NPW];
+#pragma unroll
+                    for (int i = 0; i < NRW; ++i) fa[i] = f[(size_t)(k * NF + NRW * wr + i) * 64 + lane];
+#pragma unroll
+                    for (int j = 0; j < NPW; ++j) fb[j] = f[(size_t)(k * NF + RTW + NPW * wp + j) * 64 + lane];
+#pragma unroll
+                    for (int i = 0; i < NRW; ++i) w[h][i] = *(const v4f*)(sc + (k * NF + NRW * wr + i) * 16 + 4 * q);
+#pragma unroll
+                    for (int j = 0; j < NPW; ++j) x[h][j] = sc[(k * NF + RTW + NPW * wp + j) * 16 + s];
+#pragma unroll
+                    for (int i = 0; i < NRW; ++i)
+#pragma unroll
+                        for (int j = 0; j < NPW; ++j)
+                            cc[h][i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], (v4i){0, 0, 0, 0}, 0, 0, 0);
+                }
+                pk2 t01[HS][NRW][NPW], t23[HS][NRW][NPW];
+#pragma unroll
+                for (int h = 0; h < HS; ++h)
+#pragma unroll
+                    for (int i = 0; i < NRW; ++i)
+#pragma unroll
+                        for (int j = 0; j < NPW; ++j) {
+                            const v4i c = cc[h][i][j];
+                            // tensor.rs:59  ((dot as f32) * ws) * xs; pairs (rows 4q, 4q+1), (4q+2, 4q+3)
+                            pk2 u01 = (pk2){(float)c.x, (float)c.y} * (pk2){w[h][i].x, w[h][i].y};
+                            pk2 u23 = (pk2){(float)c.z, (float)c.w} * (pk2){w[h][i].z, w[h][i].w};
+                            asm("" : "+v"(u01)); asm("" : "+v"(u23));
+                            pk2 xb = (pk2){x[h][j], x[h][j]};
+                            asm("" : "+v"(xb));
+                            u01 = u01 * xb; u23 = u23 * xb;
+                            asm("" : "+v"(u01)); asm("" : "+v"(u23));
+                            t01[h][i][j] = u01; t23[h][i][j] = u23;
+                        }
+#pragma unroll
+                for (int h = 0; h < HS; ++h)
+#pragma unroll
+                    for (int i = 0; i < NRW; ++i)
+#pragma unroll
+                        for (int j = 0; j < NPW; ++j) {
+                            v4f& ac = acc[i][j];
+                            pk2 a01 = (pk2){ac.x, ac.y} + t01[h][i][j], a23 = (pk2){ac.z, ac.w} + t23[h][i][j];
+                            asm("" : "+v"(a01)); asm("" : "+v"(a23));
+                            ac.x = a01.x; ac.y = a01.y; ac.z = a23.x; ac.w = a23.y;
+                        }
+            }
+        };
+        // ---- pipeline: register set of stage x is x % 2, LDS slot x % 2
+        issue(0, 0);
+        issue(1, 1);
+        commit(0, 0);
+        issue(0, 2);
+        __syncthreads();
+        for (int s0 = 0; s0 < nst; s0 += 2) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int st = s0 + u;
+                compute(u);                                      // stage st from LDS slot st % 2
+                commit(u ^ 1, u ^ 1);                            // stage st + 1 (requested two stages ago) -> the other slot
+                issue(u ^ 1, st + 3);
+                __syncthreads();                                 // stage st + 1 visible; slot st % 2 free for stage st + 2
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- epilogue: lane (s, q) owns out[position (pb*PTW + NPW*wp + j)*16 + s][rows 4q .. 4q+3 of row tile rb*RTW + NRW*wr + i]
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) {
+            const int ptj = pb * PTW + NPW * wp + j;
+            const int sb = ptj * 16 + s;
+            if (ptj >= nptiles || sb >= a.n_streams) continue;
+            if constexpr (EPI == EPI_SWIGLU) {
+                // packed tiles alternate w1 | w3 of the same 16 hidden units            layers.rs:468-475
+                v4f o;
+                const v4f g1 = acc[0][j], up = acc[NRW - 1][j];
+                { const float den = 1.0f + q3_expf(-g1.x); o.x = (g1.x * (1.0f / den)) * up.x; }
+                { const float den = 1.0f + q3_expf(-g1.y); o.y = (g1.y * (1.0f / den)) * up.y; }
+                { const float den = 1.0f + q3_expf(-g1.z); o.z = (g1.z * (1.0f / den)) * up.z; }
+                { const float den = 1.0f + q3_expf(-g1.w); o.w = (g1.w * (1.0f / den)) * up.w; }
+                *(v4f*)(a.out0 + (size_t)sb * a.out0_stride + (size_t)(rb * (RTW / 2) + wr) * 16 + 4 * q) = o;
+            } else {
+#pragma unroll
+                for (int i = 0; i < NRW; ++i) {
+                    const int r0 = (rb * RTW + NRW * wr + i) * 16 + 4 * q;
+                    const v4f o = acc[i][j];
+                    if constexpr (EPI == EPI_QKV) {
+                        float* dst;
+                        if (r0 < a.rows0) dst = a.out0 + (size_t)sb * a.out0_stride + r0;
+                        else if (r0 < a.rows0 + a.rows1) dst = a.out1 + (size_t)sb * a.out1_stride + (r0 - a.rows0);
+                        else dst = a.out2 + (size_t)sb * a.out2_stride + (size_t)a.st[sb].pos * a.pos_stride + (r0 - a.rows0 - a.rows1);
+                        *(v4f*)dst = o;
+                    } else if constexpr (EPI == EPI_RESID) {
+                        v4f* dst = (v4f*)(a.out0 + (size_t)sb * a.out0_stride + r0);
+                        v4f x = *dst;
+                        x.x = x.x + o.x; x.y = x.y + o.y; x.z = x.z + o.z; x.w = x.w + o.w;      // layers.rs:249-259
+                        *dst = x;
+                    } else {
+                        *(v4f*)(a.out0 + (size_t)sb * a.out0_stride + r0) = o;
+                    }
+                }
+            }
+        }
+        __syncthreads();                                         // the next block's prologue overwrites slot 0
     }
 }
 
