@@ -184,7 +184,7 @@ int q3_batch_sampler_set(q3_engine* e, float temperature, float topp, const uint
 /* Zero every stream's KV cache. */
 int q3_batch_reset_kv(q3_engine* e);
 
-/* q3_prefill with the prompt walked in blocks of up to 256 consecutive positions (env Q3_PREFILL_M; blocks of <= 32 use
+/* q3_prefill with the prompt walked in blocks of up to 2,048 consecutive positions (env Q3_PREFILL_M; blocks of <= 32 use
  * the batch-32 kernels), each block ONE pass over the weights on the matrix cores; the positions read and write the engine's own KV cache (the one q3_forward uses).
  * Sequential-equivalent: cache rows and the returned first generated token are bit-identical to q3_prefill, i.e. to
  * the prompt loop of `chat` (generation.rs:116-123).  Same shape limits as q3_batch_init (Q3_ERR_UNSUPPORTED otherwise);

@@ -2319,7 +2319,7 @@ __global__ __launch_bounds__(64) void k_knorm_rope(const AttnArgs a) {
 
 // states of one prefill block: position first_pos + i takes prompt token base + i
 __global__ void k_set_prefill_states(State* st, const int32_t* prompt, int base, int first_pos, int n) {
-    const int i = threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         st[i].token = prompt[base + i];
         st[i].pos = first_pos + base + i;

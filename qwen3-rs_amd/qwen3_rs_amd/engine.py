@@ -207,7 +207,7 @@ class Transformer:
 
     def prefill(self, tokens, first_pos: int = 0, batched: bool = False) -> int:
         """chat-mode prompt loop on the device (generation.rs:116-123); returns the first generated token.
-        batched=True walks the prompt up to 256 positions per weight pass (q3_prefill_batched; Q3_PREFILL_M), same results."""
+        batched=True walks the prompt in blocks of up to 2,048 positions per weight pass (q3_prefill_batched; Q3_PREFILL_M), same results."""
         arr = (C.c_int32 * len(tokens))(*[int(t) for t in tokens])
         out = C.c_int32(-1)
         fn = self._lib.q3_prefill_batched if batched else self._lib.q3_prefill

@@ -509,7 +509,7 @@ def test_batched_prefill_is_sequential_equivalent(q3, shape_name, n_prompt, firs
 
 
 @pytest.mark.parametrize("shape_name", ["small-longctx", "qwen3-0.6b-dims-l2"])      # head_dim 64 (k_attn_gqa) / 128 (k_attn_pf)
-@pytest.mark.parametrize("block", [32, 48, 128, 256, -128, -256])
+@pytest.mark.parametrize("block", [32, 48, 128, 256, -128, -256, 512])
 def test_batched_prefill_block_sizes_agree(q3, block, shape_name, tmp_path_factory, monkeypatch):
     """Q3_PREFILL_M picks the positions per weight pass: 32 = the batch-32 kernels (k_bgemm + LDS term tile), larger blocks
     the dense kernels (k_pgemm in-lane fold, k_attn_pf).  Every block size must give the cache rows and tokens of the

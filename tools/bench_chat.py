@@ -22,6 +22,7 @@ from qwen3_rs_amd import checkpoint as ck                    # noqa: E402
 
 
 def main():
+    prefill_m = os.environ.get("Q3_PREFILL_M", "2048")
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="qwen3-4b")
     ap.add_argument("--prefill", type=int, default=2048)
@@ -53,7 +54,7 @@ def main():
             if best is None or cur[0] + cur[1] < best[0] + best[1]:
                 best = cur
         pre_s, dec_s, first, toks = best
-        # the same prompt 256 positions per weight pass (dense int8 MFMA prefill); must reproduce the sequential result exactly
+        # the same prompt in blocks of up to 2,048 positions per weight pass (dense int8 MFMA prefill, Q3_PREFILL_M); must reproduce the sequential result exactly
         t.prefill(prompt[:40], 0, batched=True)               # allocates the MFMA-ordered weight copy
         bpre_s, bfirst = None, None
         for _ in range(2):
@@ -79,7 +80,7 @@ def main():
         "decode_hbm_frac_of_8TBps_weights_plus_kv": round((nbytes + kv_bytes) / (dec_s / a.decode) / 8e12, 4),
         "decode_kv_bytes_per_token_avg": int(kv_bytes),
         "dtype": "int8 weights x int8 activations, f32 accumulate (reference order)", "data": "synthetic",
-        "config": {"workload": f"{a.shape} Q8 chat pattern: {a.prefill}-token prefill (dense: 256 positions per weight pass on int8 MFMA, sequential-equivalent) + {a.decode}-token "
+        "config": {"workload": f"{a.shape} Q8 chat pattern: {a.prefill}-token prefill (dense: blocks of up to {prefill_m} positions per weight pass on int8 MFMA, sequential-equivalent) + {a.decode}-token "
                                f"greedy decode, ctx {a.ctx}", "checkpoint_bytes": nbytes, "seed": a.seed},
         "first_token": first, "last_token": toks[-1],
     }))
