@@ -901,7 +901,7 @@ __host__ __device__ inline size_t pgemm3_slot_bytes(int ptw, int rtw, int gs) { 
 __host__ __device__ inline size_t pgemm3_smem_bytes(int ptw, int rtw, int gs) { return 2 * pgemm3_slot_bytes(ptw, rtw, gs); }
 
 template <int EPI, int PTW, int RTW, int GS>
-__global__ __launch_bounds__(kP2Threads, 4) void k_pgemm3(const BGemmArgs a) {
+__global__ __launch_bounds__(kP2Threads, (RTW == 8 ? 2 : 4)) void k_pgemm3(const BGemmArgs a) {
     constexpr int NF = RTW + PTW;                                // fragments per group: [A0..A(RTW-1)][B0..B(PTW-1)]
     constexpr int NRW = RTW / 2, NPW = PTW / 4;                  // row / position tiles per wave
     constexpr int NJ = GS * NF;                                  // fragment jobs (1 KiB each) per stage
@@ -909,7 +909,7 @@ __global__ __launch_bounds__(kP2Threads, 4) void k_pgemm3(const BGemmArgs a) {
     constexpr int NSC = GS * NF * 16;                            // scale floats per stage
     constexpr int SW = (NSC + kP2Threads - 1) / kP2Threads;      // ... per thread (1)
     constexpr size_t kSlot = (size_t)GS * ((size_t)NF * 1024 + (size_t)NF * 64);
-    static_assert(RTW == 4 || (RTW == 2 && EPI != EPI_SWIGLU), "2-row-tile workgroups: one row tile per wave");
+    static_assert(RTW == 8 || RTW == 4 || (RTW == 2 && EPI != EPI_SWIGLU), "2-row-tile workgroups: one row tile per wave");
     static_assert(SW == 1, "one scale dword per thread and stage");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1048,13 +1048,16 @@ __global__ __launch_bounds__(kP2Threads, 4) void k_pgemm3(const BGemmArgs a) {
             if (ptj >= nptiles || sb >= a.n_streams) continue;
             if constexpr (EPI == EPI_SWIGLU) {
                 // packed tiles alternate w1 | w3 of the same 16 hidden units            layers.rs:468-475
-                v4f o;
-                const v4f g1 = acc[0][j], up = acc[NRW - 1][j];
-                { const float den = 1.0f + q3_expf(-g1.x); o.x = (g1.x * (1.0f / den)) * up.x; }
-                { const float den = 1.0f + q3_expf(-g1.y); o.y = (g1.y * (1.0f / den)) * up.y; }
-                { const float den = 1.0f + q3_expf(-g1.z); o.z = (g1.z * (1.0f / den)) * up.z; }
-                { const float den = 1.0f + q3_expf(-g1.w); o.w = (g1.w * (1.0f / den)) * up.w; }
-                *(v4f*)(a.out0 + (size_t)sb * a.out0_stride + (size_t)(rb * (RTW / 2) + wr) * 16 + 4 * q) = o;
+#pragma unroll
+                for (int pr = 0; pr < NRW / 2; ++pr) {
+                    v4f o;
+                    const v4f g1 = acc[2 * pr][j], up = acc[2 * pr + 1][j];
+                    { const float den = 1.0f + q3_expf(-g1.x); o.x = (g1.x * (1.0f / den)) * up.x; }
+                    { const float den = 1.0f + q3_expf(-g1.y); o.y = (g1.y * (1.0f / den)) * up.y; }
+                    { const float den = 1.0f + q3_expf(-g1.z); o.z = (g1.z * (1.0f / den)) * up.z; }
+                    { const float den = 1.0f + q3_expf(-g1.w); o.w = (g1.w * (1.0f / den)) * up.w; }
+                    *(v4f*)(a.out0 + (size_t)sb * a.out0_stride + (size_t)(rb * (RTW / 2) + wr * (NRW / 2) + pr) * 16 + 4 * q) = o;
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < NRW; ++i) {
