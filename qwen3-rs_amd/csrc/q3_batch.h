@@ -901,7 +901,7 @@ __host__ __device__ inline size_t pgemm3_slot_bytes(int ptw, int rtw, int gs) { 
 __host__ __device__ inline size_t pgemm3_smem_bytes(int ptw, int rtw, int gs) { return 2 * pgemm3_slot_bytes(ptw, rtw, gs); }
 
 template <int EPI, int PTW, int RTW, int GS>
-__global__ __launch_bounds__(kP2Threads, (RTW == 8 ? 2 : 4)) void k_pgemm3(const BGemmArgs a) {
+__global__ __launch_bounds__(kP2Threads, 4) void k_pgemm3(const BGemmArgs a) {
     constexpr int NF = RTW + PTW;                                // fragments per group: [A0..A(RTW-1)][B0..B(PTW-1)]
     constexpr int NRW = RTW / 2, NPW = PTW / 4;                  // row / position tiles per wave
     constexpr int NJ = GS * NF;                                  // fragment jobs (1 KiB each) per stage
@@ -963,64 +963,70 @@ __global__ __launch_bounds__(kP2Threads, (RTW == 8 ? 2 : 4)) void k_pgemm3(const
         for (int i = 0; i < NRW; ++i)
 #pragma unroll
             for (int j = 0; j < NPW; ++j) acc[i][j] = (v4f){-0.0f, -0.0f, -0.0f, -0.0f};    // Iterator::sum::<f32>() identity
-        // a stage is computed HS groups at a time (their reads, MFMAs and multiply chains are independent and overlap; all GS at once
-        // needs ~155 VGPRs), the ordered adds of a sub-step follow its terms
+        // a stage is computed HS groups x IS row tiles at a time (their reads, MFMAs and multiply chains are independent and overlap;
+        // everything at once needs ~155 VGPRs), the ordered adds of a sub-step follow its terms.  Per accumulator the order is
+        // unchanged: groups ascending.
         constexpr int HS = (GS >= 2 && NPW == 1) ? 2 : 1;
+        constexpr int IS = NRW > 2 ? 2 : NRW;
         auto compute = [&](int ls) {
             const v4i* f = slot_frag(ls);
             const float* sc = slot_sc(ls);
 #pragma unroll
             for (int k0 = 0; k0 < GS; k0 += HS) {
-                v4i cc[HS][NRW][NPW];
-                v4f w[HS][NRW];
-                float x[HS][NPW];
 #pragma unroll
-                for (int h = 0; h < HS; ++h) {
-                    const int k = k0 + h;
-                    v4i fa[NRW], fb[NPW];
+                for (int i0 = 0; i0 < NRW; i0 += IS) {
+                    v4i cc[HS][IS][NPW];
+                    v4f w[HS][IS];
+                    float x[HS][NPW];
 #pragma unroll
-                    for (int i = 0; i < NRW; ++i) fa[i] = f[(size_t)(k * NF + NRW * wr + i) * 64 + lane];
+                    for (int h = 0; h < HS; ++h) {
+                        const int k = k0 + h;
+                        v4i fa[IS], fb[NPW];
 #pragma unroll
-                    for (int j = 0; j < NPW; ++j) fb[j] = f[(size_t)(k * NF + RTW + NPW * wp + j) * 64 + lane];
+                        for (int i = 0; i < IS; ++i) fa[i] = f[(size_t)(k * NF + NRW * wr + i0 + i) * 64 + lane];
 #pragma unroll
-                    for (int i = 0; i < NRW; ++i) w[h][i] = *(const v4f*)(sc + (k * NF + NRW * wr + i) * 16 + 4 * q);
+                        for (int j = 0; j < NPW; ++j) fb[j] = f[(size_t)(k * NF + RTW + NPW * wp + j) * 64 + lane];
 #pragma unroll
-                    for (int j = 0; j < NPW; ++j) x[h][j] = sc[(k * NF + RTW + NPW * wp + j) * 16 + s];
+                        for (int i = 0; i < IS; ++i) w[h][i] = *(const v4f*)(sc + (k * NF + NRW * wr + i0 + i) * 16 + 4 * q);
 #pragma unroll
-                    for (int i = 0; i < NRW; ++i)
+                        for (int j = 0; j < NPW; ++j) x[h][j] = sc[(k * NF + RTW + NPW * wp + j) * 16 + s];
 #pragma unroll
-                        for (int j = 0; j < NPW; ++j)
-                            cc[h][i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], (v4i){0, 0, 0, 0}, 0, 0, 0);
+                        for (int i = 0; i < IS; ++i)
+#pragma unroll
+                            for (int j = 0; j < NPW; ++j)
+                                cc[h][i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], (v4i){0, 0, 0, 0}, 0, 0, 0);
+                    }
+                    pk2 t01[HS][IS][NPW], t23[HS][IS][NPW];
+#pragma unroll
+                    for (int h = 0; h < HS; ++h)
+#pragma unroll
+                        for (int i = 0; i < IS; ++i)
+#pragma unroll
+                            for (int j = 0; j < NPW; ++j) {
+                                const v4i c = cc[h][i][j];
+                                // tensor.rs:59  ((dot as f32) * ws) * xs; pairs (rows 4q, 4q+1), (4q+2, 4q+3)
+                                pk2 u01 = (pk2){(float)c.x, (float)c.y} * (pk2){w[h][i].x, w[h][i].y};
+                                pk2 u23 = (pk2){(float)c.z, (float)c.w} * (pk2){w[h][i].z, w[h][i].w};
+                                asm("" : "+v"(u01)); asm("" : "+v"(u23));
+                                pk2 xb = (pk2){x[h][j], x[h][j]};
+                                asm("" : "+v"(xb));
+                                u01 = u01 * xb; u23 = u23 * xb;
+                                asm("" : "+v"(u01)); asm("" : "+v"(u23));
+                                t01[h][i][j] = u01; t23[h][i][j] = u23;
+                            }
+#pragma unroll
+                    for (int h = 0; h < HS; ++h)
+#pragma unroll
+                        for (int i = 0; i < IS; ++i)
+#pragma unroll
+                            for (int j = 0; j < NPW; ++j) {
+                                v4f& ac = acc[i0 + i][j];
+                                pk2 a01 = (pk2){ac.x, ac.y} + t01[h][i][j], a23 = (pk2){ac.z, ac.w} + t23[h][i][j];
+                                asm("" : "+v"(a01)); asm("" : "+v"(a23));
+                                ac.x = a01.x; ac.y = a01.y; ac.z = a23.x; ac.w = a23.y;
+                            }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                pk2 t01[HS][NRW][NPW], t23[HS][NRW][NPW];
-#pragma unroll
-                for (int h = 0; h < HS; ++h)
-#pragma unroll
-                    for (int i = 0; i < NRW; ++i)
-#pragma unroll
-                        for (int j = 0; j < NPW; ++j) {
-                            const v4i c = cc[h][i][j];
-                            // tensor.rs:59  ((dot as f32) * ws) * xs; pairs (rows 4q, 4q+1), (4q+2, 4q+3)
-                            pk2 u01 = (pk2){(float)c.x, (float)c.y} * (pk2){w[h][i].x, w[h][i].y};
-                            pk2 u23 = (pk2){(float)c.z, (float)c.w} * (pk2){w[h][i].z, w[h][i].w};
-                            asm("" : "+v"(u01)); asm("" : "+v"(u23));
-                            pk2 xb = (pk2){x[h][j], x[h][j]};
-                            asm("" : "+v"(xb));
-                            u01 = u01 * xb; u23 = u23 * xb;
-                            asm("" : "+v"(u01)); asm("" : "+v"(u23));
-                            t01[h][i][j] = u01; t23[h][i][j] = u23;
-                        }
-#pragma unroll
-                for (int h = 0; h < HS; ++h)
-#pragma unroll
-                    for (int i = 0; i < NRW; ++i)
-#pragma unroll
-                        for (int j = 0; j < NPW; ++j) {
-                            v4f& ac = acc[i][j];
-                            pk2 a01 = (pk2){ac.x, ac.y} + t01[h][i][j], a23 = (pk2){ac.z, ac.w} + t23[h][i][j];
-                            asm("" : "+v"(a01)); asm("" : "+v"(a23));
-                            ac.x = a01.x; ac.y = a01.y; ac.z = a23.x; ac.w = a23.y;
-                        }
             }
         };
         // ---- pipeline: register set of stage x is x % 2, LDS slot x % 2

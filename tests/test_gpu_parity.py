@@ -509,18 +509,21 @@ def test_batched_prefill_is_sequential_equivalent(q3, shape_name, n_prompt, firs
 
 
 @pytest.mark.parametrize("shape_name", ["small-longctx", "qwen3-0.6b-dims-l2"])      # head_dim 64 (k_attn_gqa) / 128 (k_attn_pf)
-@pytest.mark.parametrize("block", [32, 48, 128, 256, -128, -256, 512])
+@pytest.mark.parametrize("block", [32, 48, 128, 256, -128, -256, 512, -512])
 def test_batched_prefill_block_sizes_agree(q3, block, shape_name, tmp_path_factory, monkeypatch):
     """Q3_PREFILL_M picks the positions per weight pass: 32 = the batch-32 kernels (k_bgemm + LDS term tile), larger blocks
     the dense kernels (k_pgemm in-lane fold, k_attn_pf).  Every block size must give the cache rows and tokens of the
     sequential prompt loop (generation.rs:116-123) bit for bit, including a ragged last block and a non-zero start.
     Blocks of 128 / 256 run the LDS-tiled matmul k_pgemm2 with 4 x 4 position-tile workgroups by default on these shapes;
     negative block: the same size with its other forms -- -128: 2 row tiles per workgroup (Q3_PGEMM2_RT=2), -256: 4 x 8 tiles
-    (Q3_PGEMM2_PT=8); 48 positions (3 tiles) stay on k_pgemm."""
+    (Q3_PGEMM2_PT=8), -512: 8 x 8 tiles (Q3_PGEMM3_RT=8); 48 positions (3 tiles) stay on k_pgemm."""
     if block == -128:
         monkeypatch.setenv("Q3_PGEMM2_RT", "2")
     if block == -256:
         monkeypatch.setenv("Q3_PGEMM2_PT", "8")
+    if block == -512:                                   # 8 x 8 workgroup tiles (k_pgemm3<.., 8, 8, 1>)
+        monkeypatch.setenv("Q3_PGEMM2_PT", "8")
+        monkeypatch.setenv("Q3_PGEMM3_RT", "8")
     block = abs(block)
     ck = q3.checkpoint
     shape = ck.SHAPES[shape_name]
