@@ -2146,13 +2146,22 @@ __global__ __launch_bounds__(64 * NP * (KVM / 2), NP * (KVM / 2) / 4) void k_att
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < DS / 4; ++j) {
-                    const float kk[4] = {kc[j].x, kc[j].y, kc[j].z, kc[j].w};
-                    const float ll[4] = {lc[j].x, lc[j].y, lc[j].z, lc[j].w};
+                    // the (z, w) halves as opaque register pairs: picked out of the float4, hipcc copied every .w element into an even
+                    // register before the multiply instead of broadcasting it by op_sel (64 v_mov per chunk on 512 packed operations)
+                    v2f kzw = {kc[j].z, kc[j].w}, lzw = {lc[j].z, lc[j].w};
+                    asm("" : "+v"(kzw));
+                    asm("" : "+v"(lzw));
+                    const float kk[4] = {kc[j].x, kc[j].y, kzw.x, kzw.y};
+                    const float ll[4] = {lc[j].x, lc[j].y, lzw.x, lzw.y};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const v2f qq = {qc[8 * j + 2 * i], qc[8 * j + 2 * i + 1]};
-                        d = d + qq * (v2f){kk[i], kk[i]};
-                        e = e + qq * (v2f){ll[i], ll[i]};
+                        // both products, then both adds: a packed multiply feeding the very next instruction costs an s_nop (81 per chunk)
+                        v2f pd = qq * (v2f){kk[i], kk[i]}, pe = qq * (v2f){ll[i], ll[i]};
+                        __builtin_amdgcn_sched_barrier(0);
+                        d = d + pd;
+                        e = e + pe;
+                        __builtin_amdgcn_sched_barrier(0);         // (left alone the scheduler batches four multiplies, then four adds two apart)
                     }
                 }
                 asm volatile("" : "+v"(d), "+v"(e));               // pure arithmetic is not ordered by sched_barrier: pin the chains to their stage
