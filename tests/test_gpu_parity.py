@@ -41,6 +41,43 @@ def test_quantize_bitexact(ops, oracle, G):
     assert_biteq(ops.dequantize(qa, sa, G), oracle.dequantize(qb, sb, G), "dequantize")
 
 
+@pytest.mark.parametrize("G", [64, 32])
+def test_quantize_half_integer_quotients_and_extreme_scales(ops, oracle, G):
+    """tensor.rs:108-111 `(x / scale).round() as i8` on the inputs where a shortcut would show: every group holds quotients AT and a
+    few ulps around k + 0.5 for every k, both signs -- the exact ties that round-half-away and round-half-even disagree on, and
+    their neighbours, where a reciprocal-multiply differs from the IEEE division -- under scales from 1e-38 to 1e38, plus denormal
+    and huge values.  (Round 4 measured such a shortcut -- x * rcp(scale), nearest-even, exact path behind a 2^-20 |q| guard: it
+    passes this test and is no faster anywhere, 1.6 % slower on the 8B shape; the device keeps the IEEE division.)"""
+    rng = np.random.default_rng(7 + G)
+    groups = []
+    for gi in range(600):
+        e = rng.uniform(-37.5, 37.5) if gi % 3 else rng.choice([-37.9, -30.0, 0.0, 30.0, 37.9])
+        wmax = np.float32(10.0 ** e) * np.float32(rng.uniform(1.0, 2.0))
+        scale = np.float32(wmax / np.float32(127.0))
+        k = rng.integers(0, 127, G).astype(np.float32)
+        q = (k + np.float32(0.5)).astype(np.float32)                       # target quotients k + 0.5
+        x = (q * scale).astype(np.float32)
+        steps = rng.integers(-3, 4, G)                                     # a few ulps either side of the tie
+        x = np.nextafter(x, np.where(steps > 0, np.float32(np.inf), np.float32(-np.inf)).astype(np.float32)).astype(np.float32) if gi % 2 else x
+        for _ in range(2):
+            x = np.where(np.abs(steps) > 1, np.nextafter(x, np.where(steps > 0, np.float32(np.inf), np.float32(-np.inf)).astype(np.float32)), x).astype(np.float32)
+        x *= rng.choice([-1.0, 1.0], G).astype(np.float32)
+        x[0] = wmax if gi % 4 else -wmax                                   # pins the group maximum (so the scale is the one above)
+        x = np.clip(x, -wmax, wmax).astype(np.float32)
+        groups.append(x)
+    groups.append(np.full(G, 1e-45, np.float32))                           # denormals only
+    groups.append(np.concatenate([[np.float32(3e38)], rng.standard_normal(G - 1).astype(np.float32) * np.float32(1e38)]).astype(np.float32))
+    groups.append(np.concatenate([[np.float32(1.0)], np.full(G - 1, 1e-42, np.float32)]).astype(np.float32))
+    x = np.concatenate(groups).astype(np.float32)
+    pad = (-len(x)) % 1024
+    x = np.concatenate([x, np.zeros(pad, np.float32)])
+    qa, sa = ops.quantize(x, G)
+    qb, sb = oracle.quantize(x, G)
+    assert_biteq(sa, sb, "scales")
+    bad = np.nonzero(qa != qb)[0]
+    assert bad.size == 0, f"{bad.size} quantized values differ, first at {bad[:5]}: x={x[bad[:5]]} device={qa[bad[:5]]} oracle={qb[bad[:5]]}"
+
+
 @pytest.mark.parametrize("n,d,G", [(64, 40, 16), (1024, 2048, 64), (2048, 1024, 64), (3072, 1024, 64), (2560, 96, 64),
                                    (9728, 24, 64), (12288, 16, 64), (4096, 100, 128), (1024, 333, 32), (128, 1, 64),
                                    (1024, 151936 // 8, 64)])
