@@ -2335,6 +2335,107 @@ __global__ __launch_bounds__(64) void k_knorm_rope(const AttnArgs a) {
     for (int i = lane; i < hd; i += 64) krow[i] = dst[i];
 }
 
+// The same for a long block (dense prefill): k_knorm_rope spends one wave on every (head, position) vector and all 64 lanes walk the
+// same 128-add chain -- 82k waves per layer at 2,048 positions of the 4B shape, ~60 us.  Here a 256-thread workgroup takes 64
+// vectors: staged in LDS (row stride 132 floats: the float4 reads of 16 chain lanes cover all 64 banks), lane l of wave 0 folds the
+// squares of vector l in index order (layers.rs:113: the same multiply, the same 128 adds from -0.0), then all threads normalise and
+// rotate element pairs with the expressions of wave_norm_rope (layers.rs:117, 181-182).  head_dim 128 only; vectors are numbered
+// position-major: v = position * (kv heads + query heads) + head slot, kv heads first.
+constexpr int kKnbVec = 64, kKnbLd = 132;
+__host__ __device__ inline size_t knorm_blk_smem_bytes() { return 4 * ((size_t)kKnbVec * kKnbLd + kKnbVec); }
+__global__ __launch_bounds__(256) void k_knorm_rope_blk(const AttnArgs a, int n_pos, int with_q) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int hd = kG2Hd, half = hd / 2;
+    float* raw = (float*)smem_raw;                                 // [64][132]
+    float* fv = raw + kKnbVec * kKnbLd;                            // [64] RMSNorm factors
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hs_n = a.n_kv_heads + (with_q ? a.n_heads : 0);
+    const long nvec = (long)n_pos * hs_n;
+    const long v0 = (long)blockIdx.x * kKnbVec;
+    auto vec_src = [&](long v, int& p, int& hs) -> const float* {
+        p = (int)(v / hs_n);
+        hs = (int)(v - (long)p * hs_n);
+        return hs < a.n_kv_heads ? a.k_raw + (size_t)p * a.sb_kraw + (size_t)hs * hd
+                                 : a.q + (size_t)p * a.sb_q + (size_t)(hs - a.n_kv_heads) * hd;
+    };
+    // ---- stage: 8 vectors per pass, 32 threads x float4 per vector
+    const int sv = tid >> 5, c4 = tid & 31;
+    v4f st[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const long v = min(v0 + 8 * k + sv, nvec - 1);
+        int p, hs;
+        const float* src = vec_src(v, p, hs);
+        st[k] = ((const v4f*)src)[c4];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) *(v4f*)(raw + (size_t)(8 * k + sv) * kKnbLd + 4 * c4) = st[k];
+    __syncthreads();
+    // ---- sum of squares, one chain per vector (wave 0)
+    if (wave == 0) {
+        const v4f* r4 = (const v4f*)(raw + (size_t)lane * kKnbLd);
+        float ss = -0.0f;
+        v4f cur[8], nxt[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cur[u] = r4[u];
+#pragma unroll
+        for (int b = 0; b < hd / 32; ++b) {
+            if (b + 1 < hd / 32) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) nxt[u] = r4[8 * (b + 1) + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const v4f x = cur[u];
+                float q = x.x * x.x; ss = ss + q;                  // layers.rs:113
+                q = x.y * x.y; ss = ss + q;
+                q = x.z * x.z; ss = ss + q;
+                q = x.w * x.w; ss = ss + q;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+        }
+        fv[lane] = 1.0f / sqrtf(ss / (float)hd + kEps);
+    }
+    __syncthreads();
+    // ---- normalise + rotate: 32 threads per vector, pairs (i, i + 64) for i = c4 and c4 + 32
+#pragma unroll 2
+    for (int k = 0; k < 8; ++k) {
+        const int vl = 8 * k + sv;
+        const long v = v0 + vl;
+        if (v >= nvec) continue;
+        int p, hs;
+        (void)vec_src(v, p, hs);
+        const bool is_q = hs >= a.n_kv_heads;
+        const float* w = is_q ? a.q_norm_w : a.k_norm_w;
+        const int pos = a.st[p].pos;
+        const float* cs = a.rope + (size_t)pos * hd;
+        const float f = fv[vl];
+        const float* src = raw + (size_t)vl * kKnbLd;
+        float* dst_lo;
+        int dstep;
+        if (is_q) {
+            const int h = hs - a.n_kv_heads;
+            dst_lo = a.q_out + ((size_t)p * a.n_heads + (size_t)(h & ~1)) * hd + (h & 1);     // pair-interleaved: [d][2]
+            dstep = 2;
+        } else {
+            dst_lo = a.key_cache + (size_t)pos * ((size_t)a.n_kv_heads * hd) + (size_t)hs * hd;
+            dstep = 1;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = c4 + 32 * u;
+            const float xv = w[i] * (f * src[i]);
+            const float yv = w[i + half] * (f * src[i + half]);
+            const float c = cs[2 * i], sn = cs[2 * i + 1];
+            const float a0 = xv * c, b0 = yv * sn;
+            const float a1 = xv * sn, b1 = yv * c;
+            dst_lo[(size_t)dstep * i] = a0 - b0;                   // layers.rs:181-182
+            dst_lo[(size_t)dstep * (i + half)] = a1 + b1;
+        }
+    }
+}
+
 // states of one prefill block: position first_pos + i takes prompt token base + i
 __global__ void k_set_prefill_states(State* st, const int32_t* prompt, int base, int first_pos, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
