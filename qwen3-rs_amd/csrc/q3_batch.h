@@ -146,7 +146,12 @@ __global__ __launch_bounds__(kWG) void k_bquant_split(const GemvArgs a, const BQ
         float ss;
         if (a.strict) {
             __syncthreads();
-            ss = seq_sum_terms(sq, n);
+            if (tid < 64) {                                // (one wave: see gemv_prologue_finish)
+                ss = seq_sum_terms(sq, n);
+                if (tid == 0) red[0] = ss;
+            }
+            __syncthreads();
+            ss = red[0];
         } else {
             ss = block_sum_fast(part_sum, red);
         }

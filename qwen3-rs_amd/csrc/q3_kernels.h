@@ -684,7 +684,14 @@ __device__ __forceinline__ void gemv_prologue_finish(const GemvArgs& a, const Ge
     if (a.strict) {
         stamp(a, 6);
         __syncthreads();
-        ss = seq_sum_terms(sm.xf, n, have_approx ? sm.red + 64 : nullptr);
+        // one wave walks the exact sum, the others wait: every wave repeating it (the r02 form) costs nothing on a lone latency-bound
+        // workgroup but is three quarters of the sum's instructions where thousands of these workgroups queue (dense prefill prologues)
+        if (tid < 64) {
+            ss = seq_sum_terms(sm.xf, n, have_approx ? sm.red + 64 : nullptr);
+            if (tid == 0) sm.red[0] = ss;
+        }
+        __syncthreads();
+        ss = sm.red[0];
         stamp(a, 7);
     } else {
         ss = block_sum_fast(part, sm.red);
