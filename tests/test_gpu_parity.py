@@ -582,6 +582,31 @@ def test_batched_prefill_block_sizes_agree(q3, block, shape_name, tmp_path_facto
         assert_biteq(t.read_state("value"), want_v, f"value cache, block {block}")
 
 
+@pytest.mark.parametrize("n_block", [81, 97, 255, 257, 383])
+def test_dense_prefill_ragged_block_lengths(q3, n_block, tmp_path_factory):
+    """One dense block of n positions for n around the kernels' switch points: 81 is the shortest dense block (6 position tiles), 97 is
+    odd (a ragged last position tile; 97 x 24 head vectors = 36 full workgroups + 24 vectors of k_knorm_rope_blk), 255 / 257 straddle the
+    prologue launches' switch from four workgroups per position to one, 383 leaves position tiles and 8-tile groups ragged at once.  K / V
+    rows, the first token and five more against the sequential prompt loop (generation.rs:116-123), bit for bit."""
+    ck = q3.checkpoint
+    shape = ck.SHAPES["qwen3-0.6b-dims-l2"]
+    path = str(tmp_path_factory.mktemp("prer") / "m.bin")
+    ck.write_synthetic_checkpoint(path, shape, seed=77)
+    prompt = ck.iter_prompt_tokens(shape, 11, 5 + n_block)
+    with q3.TransformerBuilder(path).with_ctx_length(512).build() as t:
+        t.prefill(prompt[:5], 0)
+        want_first = t.prefill(prompt[5:], 5)
+        want_rest = t.generate_greedy(want_first, len(prompt), 5)
+        want_k, want_v = t.read_state("key"), t.read_state("value")
+    with q3.TransformerBuilder(path).with_ctx_length(512).build() as t:
+        t.prefill(prompt[:5], 0)
+        got_first = t.prefill(prompt[5:], 5, batched=True)
+        assert got_first == want_first
+        assert t.generate_greedy(got_first, len(prompt), 5) == want_rest
+        assert_biteq(t.read_state("key"), want_k, f"key cache, {n_block} positions")
+        assert_biteq(t.read_state("value"), want_v, f"value cache, {n_block} positions")
+
+
 def test_batched_prefill_kv_and_token_vs_oracle(q3, oracle, tmp_path_factory):
     """The batched (int8 MFMA, 32 positions per weight pass) prefill against the ORACLE directly, not only against the
     sequential HIP path: every K/V row of a 70-token chat-mode prompt (generation.rs:116-123) and the first generated
