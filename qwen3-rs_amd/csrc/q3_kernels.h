@@ -2695,41 +2695,50 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
             o_s = o_s + x.z;
             o_s = o_s + x.w;
         };
-        v4f av[4], bv[4];
+        // Operands run 32 timesteps ahead of the adds (two sets of 8 float4): a dependent v_add_f32 issues every ~4.9 cycles
+        // (tools/mfma_chain_probe.hip; the "10 cycles" of rounds 2-3 included the timer's own latency over a 64-step loop), so the
+        // 16 adds that used to cover an LDS read were 78 cycles against a ~130-cycle round trip, and the chain ran at 11.3 per step.
+        v4f av[8], bv[8];
         {
             const v4f* v0 = (const v4f*)(vbuf0 + row * VLD);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) av[u] = v0[u];
+            for (int u = 0; u < 8; ++u) av[u] = v0[u];
         }
         for (int c0 = 0, buf = 0; c0 < np; c0 += K, buf ^= 1) {
             const int cnt = min(K, np - c0);
-            const int nq8 = ((cnt + 31) >> 5) << 3;          // float4 steps, whole blocks of 8 (zero padded, <= K/4)
+            const int nq16 = ((cnt + 63) >> 6) << 4;         // float4 steps, whole blocks of 16 (zero padded, <= K/4)
             const v4f* vr = (const v4f*)(vbuf0 + buf * (K + kVPad) * w + row * VLD);
             const v4f* vn = (const v4f*)(vbuf0 + (buf ^ 1) * (K + kVPad) * w + row * VLD);
             int q = 0;
-            for (; q + 8 < nq8; q += 8) {                    // every 32-timestep block but the chunk's last: one basic block
+            for (; q + 16 < nq16; q += 16) {                 // every 64-timestep block but the chunk's last: one basic block
+                // the chain is bound by the wave's issue rate (one instruction per ~4.9 cycles): a burst of 8 reads, ONE wait for the
+                // set requested a phase ago, 32 adds -- 1.28 instructions per timestep (a read + a wait behind every fourth add: 1.5)
+                // (the explicit lgkmcnt(8) = "everything but the burst just issued has landed": without it hipcc waits once per float4)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { bv[u] = vr[q + 4 + u]; fold4(av[u]); }
+                for (int u = 0; u < 8; ++u) bv[u] = vr[q + 8 + u];
+                __builtin_amdgcn_s_waitcnt(0xC87F);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { av[u] = vr[q + 8 + u]; fold4(bv[u]); }
-                // one LDS read in the issue slot behind every fourth add: the reads of a block issued back to back cost the
-                // chain ~3 cycles per timestep (a dependent add issues every 10 cycles, anything else fits in between)
+                for (int u = 0; u < 8; ++u) fold4(av[u]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                }
+                for (int u = 0; u < 8; ++u) av[u] = vr[q + 16 + u];
+                __builtin_amdgcn_s_waitcnt(0xC87F);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) fold4(bv[u]);
+                __builtin_amdgcn_sched_barrier(0);
             }
             {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { bv[u] = vr[q + 4 + u]; fold4(av[u]); }
+                for (int u = 0; u < 8; ++u) { bv[u] = vr[q + 8 + u]; fold4(av[u]); }
                 __syncthreads();                             // the staging waves' barrier of this chunk: tile c+1 is complete
                 if (c0 + K < np) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) av[u] = vn[u];
+                    for (int u = 0; u < 8; ++u) av[u] = vn[u];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) fold4(bv[u]);
+                for (int u = 0; u < 8; ++u) fold4(bv[u]);
             }
         }
     } else

@@ -9,7 +9,7 @@ from qwen3_rs_amd import checkpoint as ck
 pos = int(sys.argv[1]); name = sys.argv[2] if len(sys.argv) > 2 else "qwen3-0.6b"
 sh = ck.SHAPES[name]; path = f"/tmp/q3_{name}.bin"
 ck.ensure_synthetic_checkpoint(path, sh, seed=1234)
-t = q3.TransformerBuilder(path).with_ctx_length(1024).build()
+t = q3.TransformerBuilder(path).with_ctx_length(int(os.environ.get("Q3_CTX", "1024"))).build()
 t.generate_greedy(5, 0, pos)          # fill the cache up to pos
 print(f"--- stamps for positions {pos}..{pos + 7}", file=sys.stderr)
 t.generate_greedy(5, pos, 8)
