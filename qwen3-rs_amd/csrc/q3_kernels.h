@@ -1917,10 +1917,13 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
                     // past the context (inside the last float4) p = +0.0 and R holds the finite row pos again: the term
                     // is +-0.0 and o + (+-0.0) == o (o starts from +0.0 and is never -0.0)
                     const v4f pv = pq[u4];
-                    float pr = pv.x * R[4 * u4 + 0]; o = o + pr;
-                    pr = pv.y * R[4 * u4 + 1]; o = o + pr;
-                    pr = pv.z * R[4 * u4 + 2]; o = o + pr;
-                    pr = pv.w * R[4 * u4 + 3]; o = o + pr;
+                    typedef float pk2f __attribute__((ext_vector_type(2)));
+                    const pk2f t01 = (pk2f){pv.x, pv.y} * (pk2f){R[4 * u4 + 0], R[4 * u4 + 1]};      // (two products per instruction)
+                    const pk2f t23 = (pk2f){pv.z, pv.w} * (pk2f){R[4 * u4 + 2], R[4 * u4 + 3]};
+                    o = o + t01.x;
+                    o = o + t01.y;
+                    o = o + t23.x;
+                    o = o + t23.y;
                 }
             }
         };
@@ -2048,12 +2051,17 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
+                    // two products per v_pk_mul_f32 (each rounded on its own, as layers.rs:397), then the four adds of the chain:
+                    // a chain costs its instruction count x ~4.9 cycles (tools/mfma_chain_probe.hip): 7 instead of 9 per float4
                     const v4f qv = qa[u];
                     const v4f kk = kr[8 * b + u];
-                    float p = qv.x * kk.x; dot = dot + p;
-                    p = qv.y * kk.y; dot = dot + p;
-                    p = qv.z * kk.z; dot = dot + p;
-                    p = qv.w * kk.w; dot = dot + p;
+                    typedef float pk2f __attribute__((ext_vector_type(2)));
+                    const pk2f p01 = (pk2f){qv.x, qv.y} * (pk2f){kk.x, kk.y};
+                    const pk2f p23 = (pk2f){qv.z, qv.w} * (pk2f){kk.z, kk.w};
+                    dot = dot + p01.x;
+                    dot = dot + p01.y;
+                    dot = dot + p23.x;
+                    dot = dot + p23.y;
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
