@@ -340,9 +340,10 @@ __device__ __forceinline__ float chain4(float s, v4f v) {
     s = s + v.x; s = s + v.y; s = s + v.z; s = s + v.w;
     return s;
 }
-// nq = number of float4 in the run; p 16-byte aligned.  A dependent v_add_f32 costs 9 cycles and an LDS read ~60
-// on gfx950, and with one wave per SIMD nothing hides either: operands are pulled in 8-float4 blocks, the next
-// block in flight while the current one (32 adds = 288 cycles) is folded.  64 VGPRs, no more (occupancy).
+// nq = number of float4 in the run; p 16-byte aligned (LDS).  A chain advances at the wave's issue rate -- ~4.9 cycles per
+// INSTRUCTION (tools/mfma_chain_probe.hip), not per dependent add -- so what counts is instructions per add: operands are pulled
+// in bursts of 8 float4, the next burst in flight while the current 32 adds run, and ONE explicit lgkmcnt(8) per burst says "all
+// but the burst just issued has landed" (left alone hipcc waits once per float4: 1.5 instead of 1.28 instructions per add).
 __device__ __forceinline__ float seq_chain(float s, const v4f* p, int nq) {
     int q = 0;
     if (nq >= 8) {
@@ -352,14 +353,22 @@ __device__ __forceinline__ float seq_chain(float s, const v4f* p, int nq) {
         for (; q + 16 <= nq; q += 16) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) b[k] = p[q + 8 + k];
+            __builtin_amdgcn_s_waitcnt(0xC87F);                  // lgkmcnt(8)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 8; ++k) s = chain4(s, a[k]);
+            __builtin_amdgcn_sched_barrier(0);
             if (q + 24 <= nq) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) a[k] = p[q + 16 + k];
+                __builtin_amdgcn_s_waitcnt(0xC87F);
+            } else {
+                __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): the last burst
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 8; ++k) s = chain4(s, b[k]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (q + 8 <= nq) {
 #pragma unroll
