@@ -219,7 +219,7 @@ struct BGemmArgs {
 //      16-row tile is 64 KiB of weights in flight per CU), runs its MFMAs and writes the f32 group terms
 //      ((f32)idot * ws) * xs to LDS  [term tile: PG groups x 32 streams x 16 rows];
 //   2. after a barrier each of the 512 threads owns one (stream, row) accumulator and folds that accumulator's PG
-//      terms in ascending group order (the strict chain of tensor.rs:53-60, 9 cycles per add), while the next
+//      terms in ascending group order (the strict chain of tensor.rs:53-60), while the next
 //      phase's fragments are already in flight.
 // The contraction is therefore parallel over K even though every accumulator is summed strictly in order, and a
 // 256-tile matrix (4096 rows) still fills all 256 CUs with 8 waves each.

@@ -1822,7 +1822,8 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a) {
 //     then run the softmax denominator (one chain over LDS for <= 128 timesteps, the speculative scan beyond), the
 //     probabilities, and the chain o += p_t * v_t in t order (layers.rs:406-417) with p as LDS float4 bursts.
 // Every sum is in the reference's order => bit-identical to k_attn / the CPU path.  Used in both modes (the default mode's
-// tolerance is trivially met).  Measured cost of the pieces (tools/sum_probe.hip): a dependent v_add 10 cycles, a DPP
+// tolerance is trivially met).  Cost of the pieces as measured in round 2 (tools/sum_probe.hip; ~7 cycles of timer overhead per step included -- a chain really advances at
+// ~4.9 cycles per INSTRUCTION, tools/mfma_chain_probe.hip, round 4): a dependent v_add 10 cycles, a DPP
 // hop 17, v_readlane + add 23 -- which is why the long chains read their operands from LDS/VGPRs, never cross-lane.
 // ------------------------------------------------------------------------------------------------
 constexpr int kShortMaxT = 256;
@@ -1900,7 +1901,7 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
         const v4f e4 = ((const v4f*)att_e)[lane];
         float sum;
         if (np <= 128) {
-            // one chain over the (zero padded) row: np adds of 10 cycles, operands streamed from LDS as float4 -- in whole
+            // one chain over the (zero padded) row: np adds at the wave's issue rate, operands streamed from LDS as float4 -- in whole
             // batches of 8 float4 (the row is +0.0 beyond the context and s + 0.0 == s once the first exp, > 0 or +0.0, is in):
             // the batched path of seq_chain keeps the next reads in flight, its remainder loop pays an LDS round trip per float4
             sum = seq_chain(-0.0f, (const v4f*)att_e, (((np + 3) >> 2) + 7) & ~7);
@@ -2626,7 +2627,7 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
                 // transposed, rows past the context zero-filled: the accumulation below runs in whole float4 steps and
                 // p = +0.0 there, so the padded terms add +0.0 (o + 0.0 == o: o is never -0.0, it starts from +0.0)
                 // The tile holds the PRODUCTS p[t] * v[t][e]: the chain lanes then issue one LDS read and four adds per four
-                // timesteps, which keeps the issue rate under the 10-cycle dependent add (with the multiplies in the chain lane
+                // timesteps, which keeps the chain lane's instruction count down (with the multiplies in the chain lane
                 // the fold ran at ~21 cycles per timestep).
                 if (u < npass && r < kVChunk) {
                     const bool live = c0 + r < np;
