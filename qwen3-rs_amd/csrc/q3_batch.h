@@ -1620,18 +1620,20 @@ __global__ __launch_bounds__(512) void k_attn_gqa(const AttnArgs a0) {
                     for (int u = 0; u < 8; ++u) { kk[u] = k4[i + u]; qq[u] = q4[i + u]; }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        float p = qq[u].x * kk[u].x; dot = dot + p;
-                        p = qq[u].y * kk[u].y; dot = dot + p;
-                        p = qq[u].z * kk[u].z; dot = dot + p;
-                        p = qq[u].w * kk[u].w; dot = dot + p;
+                        const v4f pr = qq[u] * kk[u];          // products are independent of the chain: packed multiplies
+                        dot = dot + pr.x;
+                        dot = dot + pr.y;
+                        dot = dot + pr.z;
+                        dot = dot + pr.w;
                     }
                 }
                 for (; i < nq; ++i) {
                     const v4f kv = k4[i], qv = q4[i];
-                    float p = qv.x * kv.x; dot = dot + p;
-                    p = qv.y * kv.y; dot = dot + p;
-                    p = qv.z * kv.z; dot = dot + p;
-                    p = qv.w * kv.w; dot = dot + p;
+                    const v4f pr = qv * kv;          // products are independent of the chain: packed multiplies
+                    dot = dot + pr.x;
+                    dot = dot + pr.y;
+                    dot = dot + pr.z;
+                    dot = dot + pr.w;
                 }
                 att[t0 + t] = dot * scale;
             }

@@ -1667,18 +1667,20 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a) {
                     for (int u = 0; u < 16; ++u) { kk[u] = k4[i + u]; qq[u] = q4[i + u]; }
 #pragma unroll
                     for (int u = 0; u < 16; ++u) {
-                        float p = qq[u].x * kk[u].x; dot = dot + p;
-                        p = qq[u].y * kk[u].y; dot = dot + p;
-                        p = qq[u].z * kk[u].z; dot = dot + p;
-                        p = qq[u].w * kk[u].w; dot = dot + p;
+                        const v4f pr = qq[u] * kk[u];          // products are independent of the chain: packed multiplies
+                        dot = dot + pr.x;
+                        dot = dot + pr.y;
+                        dot = dot + pr.z;
+                        dot = dot + pr.w;
                     }
                 }
                 for (; i < nq; ++i) {
                     const v4f kv = k4[i], qv = q4[i];
-                    float p = qv.x * kv.x; dot = dot + p;
-                    p = qv.y * kv.y; dot = dot + p;
-                    p = qv.z * kv.z; dot = dot + p;
-                    p = qv.w * kv.w; dot = dot + p;
+                    const v4f pr = qv * kv;          // products are independent of the chain: packed multiplies
+                    dot = dot + pr.x;
+                    dot = dot + pr.y;
+                    dot = dot + pr.z;
+                    dot = dot + pr.w;
                 }
                 att[t0 + t] = dot * scale;
             }
@@ -2212,18 +2214,20 @@ __global__ __launch_bounds__(kWG) void k_attn_scores(const AttnArgs a) {
                 for (int u = 0; u < 16; ++u) { kk[u] = k4[i + u]; qq[u] = q4[i + u]; }
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
-                    float p = qq[u].x * kk[u].x; dot = dot + p;
-                    p = qq[u].y * kk[u].y; dot = dot + p;
-                    p = qq[u].z * kk[u].z; dot = dot + p;
-                    p = qq[u].w * kk[u].w; dot = dot + p;
+                    const v4f pr = qq[u] * kk[u];          // products are independent of the chain: packed multiplies
+                    dot = dot + pr.x;
+                    dot = dot + pr.y;
+                    dot = dot + pr.z;
+                    dot = dot + pr.w;
                 }
             }
             for (; i < nq; ++i) {
                 const v4f kv = k4[i], qv = q4[i];
-                float p = qv.x * kv.x; dot = dot + p;
-                p = qv.y * kv.y; dot = dot + p;
-                p = qv.z * kv.z; dot = dot + p;
-                p = qv.w * kv.w; dot = dot + p;
+                const v4f pr = qv * kv;          // products are independent of the chain: packed multiplies
+                dot = dot + pr.x;
+                dot = dot + pr.y;
+                dot = dot + pr.z;
+                dot = dot + pr.w;
             }
             att[t0 + t] = dot * scale;
         }
@@ -2366,10 +2370,11 @@ __global__ __launch_bounds__(kWG) void k_attn_scores_kv(const AttnArgs a) {
                 for (int u = 0; u < 16; ++u) { kk[u] = k4[i + u]; qq[u] = q4[i + u]; }
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
-                    float p = qq[u].x * kk[u].x; dot = dot + p;
-                    p = qq[u].y * kk[u].y; dot = dot + p;
-                    p = qq[u].z * kk[u].z; dot = dot + p;
-                    p = qq[u].w * kk[u].w; dot = dot + p;
+                    const v4f pr = qq[u] * kk[u];          // products are independent of the chain: packed multiplies
+                    dot = dot + pr.x;
+                    dot = dot + pr.y;
+                    dot = dot + pr.z;
+                    dot = dot + pr.w;
                 }
             }
             sc = dot * (1.0f / sqrtf((float)hd));
