@@ -293,6 +293,20 @@ static void launch_attn_scores(const AttnArgs& a, int kvm, unsigned gx, unsigned
     else hipLaunchKernelGGL(k_attn_scores, dim3(gx, gy), dim3(kWG), smem, st, a);
 }
 
+// Short-context attention (pos < 256): k_attn_short2 (round 5: coalesced key / value staging, product tile, 8 waves) for
+// head_dim 128 on caches of a whole number of 8-row steps; k_attn_short (head_dim 64, odd test contexts) otherwise.
+static bool attn_short2_ok(const AttnArgs& a) { return a.hd == 128 && a.seq_len >= 8 && (a.seq_len % 8) == 0 && a.att_short_form != 1; }
+static int set_attn_short_smem(const AttnArgs& a) {
+    if (!attn_short2_ok(a)) return Q3_OK;
+    return set_max_smem((const void*)k_attn_short2<128>, attn_short2_smem_bytes(128, kS2MaxT));
+}
+static void launch_attn_short(const AttnArgs& a, unsigned n_heads, hipStream_t st) {
+    if (attn_short2_ok(a))
+        hipLaunchKernelGGL(k_attn_short2<128>, dim3(n_heads), dim3(kS2Threads), attn_short2_smem_bytes(128, kS2MaxT), st, a);
+    else if (a.hd == 128) hipLaunchKernelGGL(k_attn_short<128>, dim3(n_heads), dim3(kWG), 0, st, a);
+    else hipLaunchKernelGGL(k_attn_short<64>, dim3(n_heads), dim3(kWG), 0, st, a);
+}
+
 // no_next: the classifier launch without the folded bookkeeping (q3_profile replays launches without advancing the state)
 void launch_one(const Launch& L, q3_engine* e, bool no_next = false) {
     if (no_next && L.fam == F_LMHEAD && L.ga.next_cell != nullptr) {
@@ -304,10 +318,7 @@ void launch_one(const Launch& L, q3_engine* e, bool no_next = false) {
     if (L.is_attn) {
         if (L.attn_kind == 1) launch_attn_scores(L.aa, L.scores_kvm, L.grid, L.grid_y, L.smem, e->stream);
         else if (L.attn_kind == 2) launch_attn_out(L.aa, L.grid, L.grid_y, L.smem, e->stream);
-        else if (L.attn_kind == 3) {
-            if (L.aa.hd == 128) hipLaunchKernelGGL(k_attn_short<128>, dim3(L.grid), dim3(kWG), 0, e->stream, L.aa);
-            else hipLaunchKernelGGL(k_attn_short<64>, dim3(L.grid), dim3(kWG), 0, e->stream, L.aa);
-        }
+        else if (L.attn_kind == 3) launch_attn_short(L.aa, L.grid, e->stream);
         else hipLaunchKernelGGL(k_attn, dim3(L.grid), dim3(kWG), L.smem, e->stream, L.aa);
     } else if (L.is_next) {
         hipLaunchKernelGGL(k_next, dim3(1), dim3(kWG), 0, e->stream, e->d_state, e->d_argmax_slots, e->n_argmax_slots,
@@ -680,7 +691,11 @@ int q3_engine::build_plan() {
             Ln.smem = attn_smem_bytes(hd, use_att_global ? 0 : S);
             if ((rc = set_max_smem((const void*)k_attn, Ln.smem))) return rc;
             // the short plan only ever runs at pos < split_pos
-            if ((hd == 64 || hd == 128) && split_pos <= kShortMaxT && env_int("Q3_ATT_SHORT", 1)) Ln.attn_kind = 3;
+            if ((hd == 64 || hd == 128) && split_pos <= kShortMaxT && env_int("Q3_ATT_SHORT", 1)) {
+                Ln.attn_kind = 3;
+                Ln.aa.att_short_form = env_int("Q3_ATT_SHORT", 1) == 2 ? 1 : 0;      // 2: the round 2-4 kernel (A/B)
+                if ((rc = set_attn_short_smem(Ln.aa))) return rc;
+            }
             // k_attn_short can hand Wo its operand quantized (qwen3.rs:152 fused into the attention epilogue)
             wo_preq = Ln.attn_kind == 3 ? find_cfg(PRO_PREQR, EPI_RESID, ahd, G, env_int("Q3_CFG_WO", 0)) : nullptr;
             if (wo_preq) {
@@ -1586,8 +1601,9 @@ int q3_op_attention(float* xb, float* q, float* key_cache_layer, const float* va
         if ((rc = op_end())) return rc;
         HIP_TRY(hipMemcpy(dq.p, dqout.p, 4 * ahd, hipMemcpyDeviceToDevice));
     } else if ((head_dim == 64 || head_dim == 128) && env_int("Q3_ATT_SHORT", 1)) {
-        if (head_dim == 128) hipLaunchKernelGGL(k_attn_short<128>, dim3((unsigned)n_heads), dim3(kWG), 0, 0, a);
-        else hipLaunchKernelGGL(k_attn_short<64>, dim3((unsigned)n_heads), dim3(kWG), 0, 0, a);
+        a.att_short_form = env_int("Q3_ATT_SHORT", 1) == 2 ? 1 : 0;
+        if ((rc = set_attn_short_smem(a))) return rc;
+        launch_attn_short(a, (unsigned)n_heads, 0);
     } else {
         const size_t smem = attn_smem_bytes((int)head_dim, att_global ? 0 : (int)seq_len);
         if ((rc = set_max_smem((const void*)k_attn, smem))) return rc;

@@ -1464,6 +1464,7 @@ struct AttnArgs {
     float* xbs;
     int xb_group;
     int n_pos;                // k_attn_pf2 (dense prefill): positions in the block
+    int att_short_form;       // host bookkeeping: 1 = keep k_attn_short where k_attn_short2 is eligible (A/B)
 };
 
 // LDS plan of k_attn (floats): q_s[hd] k_s[hd] raw[2hd] sq[2hd] opart[kWaves*hd] red[64] att[att_lds]
@@ -2109,6 +2110,7 @@ __global__ __launch_bounds__(kWG) void k_attn_short(const AttnArgs a) {
     __syncthreads();                                      // C
 }
 
+#include "q3_attn_short2.h"
 
 // ------------------------------------------------------------------------------------------------
 // Long-context attention (pos >= the host's split threshold): the same arithmetic, in the same order, spread

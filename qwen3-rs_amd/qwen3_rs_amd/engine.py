@@ -66,7 +66,7 @@ _lib: Optional[C.CDLL] = None
 
 
 def source_build_id() -> str:
-    """The id `make` bakes into the library: sha256 over csrc/* (sorted), include/qwen3_hip.h and the Makefile (compiler flags) -- first 16 hex digits."""
+    """The id `make` bakes into the library: sha256 over csrc/* (sorted), include/qwen3_hip.h and the Makefile (compiler flags) -- first 16 hex digits.  A library built with ad-hoc `EXTRA=-D...` switches carries a different id."""
     import glob
     import hashlib
     h = hashlib.sha256()
@@ -75,6 +75,7 @@ def source_build_id() -> str:
     for f in files:
         with open(f, "rb") as fh:
             h.update(fh.read())
+    h.update(b"\n")          # the Makefile appends its EXTRA switches (none for the product build) and a newline
     return h.hexdigest()[:16]
 
 
