@@ -1027,6 +1027,10 @@ __global__ __launch_bounds__(WGT) void k_gemv(const GemvArgs a) {
     constexpr int WAVES = WGT / 64;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     stamp(a, 0);
+    // (the grid width is a hidden kernel argument: left alone its scalar load sits next to its first use, a second round trip
+    // in front of the first weight request)
+    const int gdx = (int)gridDim.x;
+    Q3_PIN_S(gdx);
     Q3_PIN_S(a.in); Q3_PIN_S(a.n); Q3_PIN_S(a.group); Q3_PIN_S(a.total_rows); Q3_PIN_S(a.strict);
     Q3_PIN_S(a.seg[0].wq); Q3_PIN_S(a.seg[0].ws); Q3_PIN_S(a.seg[0].out); Q3_PIN_S(a.seg[0].rows);
     if constexpr (PRO == PRO_NORM || PRO == PRO_EMBED_NORM) Q3_PIN_S(a.norm_w);
@@ -1101,8 +1105,8 @@ __global__ __launch_bounds__(WGT) void k_gemv(const GemvArgs a) {
     // batch b of the launch belongs to wave b % nwaves.  Specialised shapes number the waves workgroup-minor, so a launch
     // with fewer row batches than waves (Wo / W2 of the small models under 16-wave workgroups) still puts rows on every CU;
     // the surplus waves only help with the prologue.
-    const int gw = kSpec ? wave * (int)gridDim.x + (int)blockIdx.x : (int)blockIdx.x * WAVES + wave;
-    const int nwaves = gridDim.x * WAVES;
+    const int gw = kSpec ? wave * gdx + (int)blockIdx.x : (int)blockIdx.x * WAVES + wave;
+    const int nwaves = gdx * WAVES;
     const int units = (EPI == EPI_SWIGLU) ? a.seg[0].rows : a.total_rows;   // rows (or hidden units)
     //   // rows (or hidden units)
     const int nb = (units + HU - 1) / HU;
@@ -1401,7 +1405,7 @@ __global__ __launch_bounds__(WGT) void k_gemv(const GemvArgs a) {
                     __hip_atomic_fetch_max(a.next_cell, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long ticket = __hip_atomic_fetch_add(a.next_cell + 1, old == ~0ull ? 2ull : 1ull,
                                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (ticket == (unsigned long long)gridDim.x - 1) {
+                if (ticket == (unsigned long long)gdx - 1) {
                     const unsigned long long best_all = __hip_atomic_load(a.next_cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const int idx = (int)(unsigned)(best_all & 0xffffffffull);
                     const int step = st->step;

@@ -6,11 +6,11 @@ the free functions of tensor.rs / layers.rs, the `generate` / `chat` call patter
 the checkpoint format (qwen3-export/src/model_exporter.rs).  All compute runs in libqwen3_hip.so
 (hand-written HIP kernels); there is no CPU fallback -- loading fails loudly if the library is missing.
 """
-from .engine import (Q3Error, ModelConfig, Transformer, TransformerBuilder, lib_path, load_library, ops,
+from .engine import (Q3Error, ModelConfig, Transformer, TransformerBuilder, lib_path, dev_lib_path, load_library, use_library, ops,
                      FLAG_FAST, FLAG_NO_GRAPH, EXPORTED_SYMBOLS, source_build_id)
 from .generation import generate, chat_turn, TokenMetrics, sample_argmax
 from . import checkpoint
 
-__all__ = ["Q3Error", "ModelConfig", "Transformer", "TransformerBuilder", "lib_path", "load_library", "ops",
+__all__ = ["Q3Error", "ModelConfig", "Transformer", "TransformerBuilder", "lib_path", "dev_lib_path", "load_library", "use_library", "ops",
            "FLAG_FAST", "FLAG_NO_GRAPH", "EXPORTED_SYMBOLS", "source_build_id", "generate", "chat_turn", "TokenMetrics",
            "sample_argmax", "checkpoint"]

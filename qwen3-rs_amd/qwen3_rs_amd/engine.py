@@ -79,12 +79,47 @@ def source_build_id() -> str:
     return h.hexdigest()[:16]
 
 
+def dev_lib_path() -> str:
+    """The developer build (`make -C qwen3-rs_amd dev`, -DQ3_DEV): the same sources plus the A/B switches (Q3_* environment
+    variables beyond the documented ones), the kernel forms that lost their A/B, ablation bits and in-kernel timelines."""
+    return os.path.join(_DIST_DIR, "libqwen3_hip_dev.so")
+
+
+_libs: dict = {}
+
+
 def load_library() -> C.CDLL:
     """Load libqwen3_hip.so.  Fails loudly: the HIP library is the product, there is nothing to fall back to."""
     global _lib
     if _lib is not None:
         return _lib
-    path = lib_path()
+    _lib = _bind(lib_path())
+    return _lib
+
+
+class use_library:
+    """Context manager: engines and operators created inside use the library at `path` (tests of the developer build's kernel
+    forms: `with q3.use_library(q3.dev_lib_path()): ...`).  Objects keep the library they were created with."""
+
+    def __init__(self, path: str):
+        self.path = path
+
+    def __enter__(self):
+        global _lib
+        self._saved = _lib
+        _lib = _bind(self.path)
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._saved
+        return False
+
+
+def _bind(path: str) -> C.CDLL:
+    path = os.path.abspath(path)
+    if path in _libs:
+        return _libs[path]
     if not os.path.exists(path):
         raise Q3Error(-1, f"{path} not found: build it with `make -C {_DIST_DIR}` (or __graft_entry__.build())")
     L = C.CDLL(path)
@@ -132,7 +167,7 @@ def load_library() -> C.CDLL:
     L.q3_op_attention.argtypes = [fp, fp, fp, fp, fp, fp, sz, sz, sz, sz, sz, C.c_uint32, C.c_int]
     L.q3_op_argmax.argtypes = [fp, sz, C.POINTER(C.c_int32), C.c_int]
     L.q3_op_sample.argtypes = [fp, sz, C.c_float, C.c_float, C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.c_int]
-    _lib = L
+    _libs[path] = L
     return L
 
 
