@@ -96,7 +96,7 @@ def pmc_traffic(shape_name):
     suffix = {"qwen3-0.6b": "", "qwen3-4b": "_4b", "qwen3-8b": "_8b", "deepseek-r1-0528-qwen3-8b": "_8b"}.get(shape_name)
     if suffix is None:
         return None
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         f = os.path.join(ROOT, "profiles", f"{rnd}_pmc_fetch_size{suffix}.json")
         if not os.path.exists(f):
             continue
@@ -282,6 +282,29 @@ def worker_main(args):
             "definition": "TokenMetrics (generation.rs:198-233) around generate_next_token (generation.rs:153-162): q3_forward "
                           "(host-synchronous, 4*vocab bytes of logits over PCIe) + logits copy + host sample_argmax, K tokens, "
                           "compiled host loop (q3_host_generate) standing in for the Rust shim"}
+        # BASELINE configs 1 / 2 are 128-token runs: both surfaces on 128 tokens whatever --steps is, so the
+        # config-true figures are in the driver's record too; and the ratio of the two surfaces with ONE policy for both legs
+        # (best of two runs each)
+        n128 = min(128, args.ctx - first_pos)
+        dev_runs, fs128_runs, tok128, fs128_tok = [], [], None, None
+        for _ in range(2):
+            eng.reset_kv()
+            t1 = time.perf_counter()
+            tok128 = eng.generate_greedy(first_tok, first_pos, n128)
+            dev_runs.append(time.perf_counter() - t1)
+        for _ in range(2):
+            eng.reset_kv()
+            fs128_tok, s1 = eng.host_generate(first_tok, first_pos, n128)
+            fs128_runs.append(s1)
+        out["value_128"] = {"value": round(n128 / min(dev_runs), 2), "unit": "tokens/s", "tokens": n128,
+                            "runs_tok_s": [round(n128 / t, 2) for t in dev_runs],
+                            "what": "the device-resident greedy loop of `value` on the 128-token run of BASELINE configs 1 / 2, best of two"}
+        out["forward_surface_128"] = {"value": round(n128 / min(fs128_runs), 2), "unit": "tokens/s", "tokens": n128,
+                                      "runs_tok_s": [round(n128 / t, 2) for t in fs128_runs],
+                                      "ratio_to_device_loop": round(min(dev_runs) / min(fs128_runs), 4),
+                                      "tokens_match_device_loop": [int(t) for t in fs128_tok] == [int(t) for t in tok128]}
+        if not out["forward_surface_128"]["tokens_match_device_loop"]:
+            out["forward_surface"]["tokens_match_device_loop"] = False
     except Exception as e:
         log(f"[bench] forward_surface failed: {e!r}")
         out["forward_surface"] = None
@@ -368,7 +391,13 @@ def cpu_baseline(path, ctx, first_tok, first_pos, gpu_tokens, max_tokens=128, bu
     m.close()
     gpu = [int(t) for t in gpu_tokens]
     ncmp, ncmp1 = min(len(toks), len(gpu)), min(len(toks1), len(gpu))
-    match = ncmp > 0 and all(r[1][:ncmp] == gpu[:ncmp] for r in runs) and toks1[:ncmp1] == gpu[:ncmp1]
+
+    def agrees(tk):            # every timed run is compared over ITS OWN length: a run the budget cut short is not a mismatch
+        k = min(len(tk), len(gpu))
+        return k > 0 and tk[:k] == gpu[:k]
+
+    match = ncmp > 0 and all(agrees(r[1]) for r in runs) and toks1[:ncmp1] == gpu[:ncmp1]
+    ncmp_min = min(min(len(r[1]), len(gpu)) for r in runs)
     sweep_best = max(r["tok_s_median"] for r in sweep)
     return {"value": rate, "unit": "tokens/s", "cores": best_c, "kind": "port",
             "sample": f"{len(toks)} generated tokens of the same workload ({dt:.1f} s; median of {len(runs)} runs: "
@@ -381,7 +410,7 @@ def cpu_baseline(path, ctx, first_tok, first_pos, gpu_tokens, max_tokens=128, bu
             "value_over_sweep_row_after": round(rate / sorted(after)[1], 3),
             "one_thread": {"value": len(toks1) / dt1, "unit": "tokens/s", "cores": 1,
                            "sample": f"first {len(toks1)} generated tokens ({dt1:.1f} s) on 1 host thread"},
-            "tokens_compared": ncmp, "tokens_match_gpu": bool(match)}, match
+            "tokens_compared": ncmp, "tokens_compared_shortest_run": ncmp_min, "tokens_match_gpu": bool(match)}, match
 
 
 def free_port():

@@ -12,6 +12,14 @@
  * GPU, no communication (replicas only -- the path does not shard).
  * Errors: 0 on success, negative q3_status otherwise; q3_last_error() gives the calling thread's
  * message.  There is NO CPU fallback: without a usable HIP device q3_create fails.
+ *
+ * Environment: libqwen3_hip.so reads exactly these variables (tests/test_host_and_abi.py checks the binary):
+ *     Q3_PREFILL_M=<16..4096>   positions per weight pass of q3_prefill_batched (default 2048; <= 32 selects the batch-32
+ *                               kernels).  The dense attention scratch grows with it: 4 * M * n_heads * context bytes.
+ *     Q3_DEBUG_TIMING=1         host-side timing of q3_forward / q3_host_generate phases on stderr.
+ * Every other Q3_* switch of earlier rounds (kernel-form A/B, tile and workgroup overrides, ablation bits, in-kernel
+ * timelines) exists only in the developer build, libqwen3_hip_dev.so (`make -C qwen3-rs_amd dev`, -DQ3_DEV), together with
+ * the kernel forms that lost their A/B; results are identical in both builds.
  */
 #ifndef QWEN3_HIP_H
 #define QWEN3_HIP_H

@@ -22,6 +22,14 @@
 //     512-byte row, and the scores must not wait for the second half of that traffic.  The staging waves commit the value
 //     tile after barrier A, raise an LDS flag and END (a finished wave no longer counts at s_barrier); the output waves,
 //     idle until the probabilities exist, poll the flag.
+//   * grid (heads, 2): past 64 positions the workgroup's time is the key + value bytes through ONE CU's memory path, so the two
+//     64-element halves of a head's output go to two workgroups (each loads every key row but only its half of the value
+//     rows: -0.15 ... -0.3 us per launch at positions 64 ... 255, profiles/r05_attn_short2.txt); up to 64 positions the second
+//     workgroup leaves as soon as it knows the position.
+//   * AttnArgs::row_steps > 0 (the host knows the position of every forward it enqueues and keeps one captured graph per position
+//     range below 64): the staging waves request that many 8-row steps of key and value rows AT KERNEL ENTRY instead of behind
+//     the position's own round trip (rows past the context are valid cache rows: requested, never committed); the launch then
+//     has ONE dependent memory round trip in front of the tiles instead of two.
 // Dynamic LDS: max_t rows x (HD + 4) floats (attn_short2_smem_bytes): product tile [t][HD + 4]; value tile [t][HD] behind row 128.
 constexpr int kS2Threads = 512;
 constexpr int kS2MaxT = 256;
@@ -30,7 +38,7 @@ __host__ __device__ inline size_t attn_short2_smem_bytes(int hd, int max_t) { re
 template <int V> struct IntC { static constexpr int value = V; };
 
 #ifdef Q3_DEV
-#define ATT2_STAMP(i, thr) do { if (a.stamps != nullptr && blockIdx.x == 3 && (int)threadIdx.x == (thr)) a.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ATT2_STAMP(i, thr) do { if (a.stamps != nullptr && (a.debug & 64) == 0 && blockIdx.x == 3 && (int)threadIdx.x == (thr)) a.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define ATT2_STAMP(i, thr) do { } while (0)
 #endif
@@ -53,6 +61,7 @@ __global__ __launch_bounds__(kS2Threads) void k_attn_short2(const AttnArgs a) {
     __shared__ unsigned vflag;                                         // staging waves that have committed their value rows
     __shared__ unsigned bcount;                                        // score waves that have published their scores ("barrier B")
     ATT2_STAMP(0, 0);
+    KSTAMP_BEGIN(a);
     Q3_PIN_S(a.st); Q3_PIN_S(a.pos_override); Q3_PIN_S(a.q); Q3_PIN_S(a.k_raw); Q3_PIN_S(a.key_cache); Q3_PIN_S(a.value_cache);
     Q3_PIN_S(a.q_norm_w); Q3_PIN_S(a.k_norm_w); Q3_PIN_S(a.rope); Q3_PIN_S(a.xb); Q3_PIN_S(a.n_heads); Q3_PIN_S(a.n_kv_heads);
     Q3_PIN_S(a.write_q);
@@ -72,7 +81,16 @@ __global__ __launch_bounds__(kS2Threads) void k_attn_short2(const AttnArgs a) {
         // ================================ output waves ================================
         const int pos = __builtin_amdgcn_readfirstlane(pos_v);
         const int np = pos + 1;
-        const int e = 64 * (wave - 4) + lane;             // output element of this lane
+        const bool vsplit = gridDim.y == 2 && np > 64;    // this workgroup owns output elements 64 y .. 64 y + 63
+        if (gridDim.y == 2 && blockIdx.y == 1 && np <= 64) return;      // (every wave of the workgroup leaves)
+        if (vsplit && wave == 5) {                        // one output wave is enough: keep the barriers company
+            __syncthreads();                              // A'
+            __syncthreads();                              // A
+            if (np > 128) __syncthreads();                // B
+            __syncthreads();                              // C
+            return;
+        }
+        const int e = vsplit ? 64 * (int)blockIdx.y + lane : 64 * (wave - 4) + lane;     // output element of this lane
         const unsigned eoff = 4u * (unsigned)e;
         float vv[kShortVSets][32];
         auto v_issue = [&](float (&R)[32], int c) {
@@ -170,6 +188,7 @@ __global__ __launch_bounds__(kS2Threads) void k_attn_short2(const AttnArgs a) {
             if ((idx & (a.xb_group - 1)) == 0) a.xbs[idx / a.xb_group] = scale;
         }
         ATT2_STAMP(6, 256);
+        KSTAMP_END(a);
         return;
     }
 
@@ -184,6 +203,7 @@ __global__ __launch_bounds__(kS2Threads) void k_attn_short2(const AttnArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         pos = __builtin_amdgcn_readfirstlane(pos_v);      // the oldest load of the wave: a counted wait
         np = pos + 1;
+        if (gridDim.y == 2 && blockIdx.y == 1 && np <= 64) return;
         const v2f cs = *(const v2f*)(a.rope + (size_t)pos * HD + 2 * lane);   // (cos, sin) of rotation pair `lane`
         ATT2_STAMP(1, 0);
         float* sq = sq_s + (is_q ? 0 : HD);
@@ -204,7 +224,7 @@ __global__ __launch_bounds__(kS2Threads) void k_attn_short2(const AttnArgs a) {
                 a.q[(size_t)h * HD + lane] = lo;
                 a.q[(size_t)h * HD + lane + HALF] = hi;
             }
-        } else if ((h % kv_mul) == 0) {                   // K is normalised + rotated in place in the cache
+        } else if ((h % kv_mul) == 0 && blockIdx.y == 0) {   // K is normalised + rotated in place in the cache
             float* krow = a.key_cache + (size_t)pos * kvd + (size_t)kvh * HD;
             krow[lane] = lo;
             krow[lane + HALF] = hi;
@@ -219,8 +239,12 @@ __global__ __launch_bounds__(kS2Threads) void k_attn_short2(const AttnArgs a) {
         // ================================ staging waves: key rows 0 .. pos-1 (value rows 0 .. pos), coalesced, into LDS
         unsigned long long etv = 0ull;
         if (wave == 7 && lane < 32) etv = kExp2Tab[lane];
-        pos = __builtin_amdgcn_readfirstlane(pos_v);
-        np = pos + 1;
+        const int hint = a.row_steps;                     // > 0: 8-row steps to request without waiting for the position (pos < 64)
+        if (hint <= 0) {
+            pos = __builtin_amdgcn_readfirstlane(pos_v);
+            np = pos + 1;
+            if (gridDim.y == 2 && blockIdx.y == 1 && np <= 64) return;
+        }
         ATT2_STAMP(8, 128);
         const int sidx = 64 * ((wave & 1) + (wave >= 6 ? 2 : 0)) + lane;     // 0 .. 255
         const int r0 = sidx >> 5, col = sidx & 31;        // 8 rows per step of the four staging waves
@@ -242,6 +266,10 @@ __global__ __launch_bounds__(kS2Threads) void k_attn_short2(const AttnArgs a) {
                 for (int k = 0; k < T; ++k) rv[k] = *(const v4f*)((const char*)(vbase + (size_t)min(k, kmax) * 8 * kvd) + loff);
             }
             ATT2_STAMP(9, 128);
+            if (hint > 0) {                               // (wave-uniform) the position arrives under the row requests
+                pos = __builtin_amdgcn_readfirstlane(pos_v);
+                np = pos + 1;
+            }
             __syncthreads();                              // A': q_s
             const v4f qv = ((const v4f*)q_s)[col];
 #pragma unroll
@@ -266,7 +294,7 @@ __global__ __launch_bounds__(kS2Threads) void k_attn_short2(const AttnArgs a) {
         };
         // tiers by context length (wave-uniform): straight-line bursts of 1 .. 32 float4 per thread and tile (a run-time trip
         // count would put every load in its own basic block, and hipcc then throttles the burst with conservative vmcnt waits)
-        const int tn = (pos + 8) >> 3;                    // 8-row steps that cover value rows 0 .. pos
+        const int tn = hint > 0 ? hint : (pos + 8) >> 3;  // 8-row steps that cover value rows 0 .. pos
         if (tn <= 1) stage(IntC<1>{}, IntC<1>{});
         else if (tn <= 2) stage(IntC<2>{}, IntC<1>{});
         else if (tn <= 3) stage(IntC<3>{}, IntC<1>{});
@@ -351,4 +379,5 @@ __global__ __launch_bounds__(kS2Threads) void k_attn_short2(const AttnArgs a) {
     att_e[t] = ev;
     if (np <= 128) att_e[t + 128] = 0.0f;                 // (waves 2, 3 are gone)
     __syncthreads();                                      // C
+    KSTAMP_END(a);
 }

@@ -127,6 +127,7 @@ typedef void (*GemvFn)(const GemvArgs);
 struct Launch {
     Family fam;
     bool is_attn = false, is_next = false;
+    bool is_kfold = false; // developer (Q3_KSTAMPS): k_kstamp_fold behind the token's last launch
     int scores_kvm = 0;    // attn_kind 1: > 0 = k_attn_scores_kv<scores_kvm> (K chunk shared by the heads of a kv head)
     int attn_kind = 0;     // 0: single-kernel attention, 1: k_attn_scores, 2: k_attn_out (long-context split),
                            // 3: k_attn_short (pos < 256, head_dim 64/128: K rows in registers, no LDS staging)
@@ -160,15 +161,23 @@ int set_max_smem(const void* fn, size_t bytes) {
     return Q3_OK;
 }
 
+// Environment variables.  The product library reads only the documented ones (include/qwen3_hip.h, "Environment"):
+// env_int().  Everything else -- A/B switches between kernel forms, tile / workgroup overrides, ablation and timeline
+// switches -- exists in the developer build only (make dev, -DQ3_DEV): dev_knob() is its default in the product.
 int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
 }
+#ifdef Q3_DEV
+#define dev_knob(name, dflt) env_int(name, dflt)
+#else
+#define dev_knob(name, dflt) (dflt)
+#endif
 // activation requests ahead of the weight requests (GemvArgs::xfirst): 2 = workgroup barrier between them, 1 = wait for wave 0's
 // block of x, 0 = program order only.  r03 A/B in reference-order mode (tools/gen_loop.py, Q3_STRICT=1): the barrier costs the QKV
 // launch 0.15 us at every shape (0.6B: 1,572 -> 1,527 tok/s), gains W13 0.4 us at dim 1024 (+0.3 %) and nothing at 2560 / 4096;
 // in Q3_FLAG_FAST mode (no exact sum in front of the quantizer) it is worth +6 % on the 0.6B shape.
-int xfirst_dflt(int wgt) { return wgt >= 1024 ? env_int("Q3_XFIRST_DEFAULT", 2) : 0; }
+int xfirst_dflt(int wgt) { return wgt >= 1024 ? dev_knob("Q3_XFIRST_DEFAULT", 2) : 0; }
 
 
 }  // namespace
@@ -197,7 +206,12 @@ struct q3_engine {
     int32_t* d_out_tokens = nullptr;
     int32_t* d_prompt = nullptr;               // chat-mode prefill: prompt token ids (capacity out_cap)
     int out_cap = 0;
-    unsigned long long* d_stamps = nullptr;   // developer timeline (Q3_STAMPS=1)
+    unsigned long long* d_stamps = nullptr;   // developer timeline (Q3_STAMPS=1) / kernel begin-end cells (Q3_KSTAMPS=1)
+    unsigned long long* d_kacc = nullptr;     // Q3_KSTAMPS=1: per-launch duration / gap sums (k_kstamp_fold)
+    unsigned long long* d_kslots = nullptr;   //   per-wave begin / end slots of every launch, [launch][kKstampSlots][2]
+    unsigned long long* d_kcells = nullptr;   //   per-launch {begin, end} of the current token (k_kstamp_reduce)
+    int* d_knslots = nullptr;                 //   live wave slots of every launch
+    bool kstamps = false;
     unsigned long long* d_argmax_slots = nullptr;
     unsigned long long* d_next_cell = nullptr;   // {argmax cell, ticket counter} of the classifier launch with k_next folded in
     int n_argmax_slots = 0;
@@ -213,6 +227,22 @@ struct q3_engine {
     // q3_forward as ONE graph launch: state upload (pinned h_state) -> the token's kernels -> logits download (pinned h_logits)
     hipGraph_t graph_fwd = nullptr, graph_fwd_long = nullptr;
     hipGraphExec_t graph_fwd_exec = nullptr, graph_fwd_long_exec = nullptr;
+    // position ranges below 64 (k_attn_short2 only; developer build, Q3_ATT_RANGES=1): one more captured pair per range, whose
+    // attention launches request their key / value rows at kernel entry (AttnArgs::row_steps) -- the host knows the position of
+    // every forward it enqueues.  Measured in round 5 (three alternations, 0.6B device loop): 577.8-582.8 us per token against
+    // 569.1-576.2 without -- the early row requests stand in the CU's address path in front of the raw q / k values the norm
+    // chains wait for.  Off; the product captures no range graphs.
+    static constexpr int kNRange = 6;
+    static constexpr int kRangeSteps[kNRange] = {1, 2, 3, 4, 6, 8};      // 8-row steps: positions < 8, 16, 24, 32, 48, 64
+    hipGraph_t graph_rng[kNRange] = {}, graph_fwd_rng[kNRange] = {};
+    hipGraphExec_t graph_rng_exec[kNRange] = {}, graph_fwd_rng_exec[kNRange] = {};
+    bool ranges = false;
+    int range_of(size_t pos) const {
+        if (!ranges) return -1;
+        for (int i = 0; i < kNRange; ++i)
+            if (pos < (size_t)(8 * kRangeSteps[i])) return i;
+        return -1;
+    }
     float* d_att_priv = nullptr;
     int cmax_stride = 0;
     int att_stride = 0;
@@ -269,7 +299,7 @@ int set_attn_out_smem(size_t bytes) {
 // k_attn_scores_kv applies to head_dim 128 with 2 or 4 query heads per kv head (every listed Qwen3 size up to 8B)
 static int scores_kvm_for(int hd, int n_heads, int n_kv_heads) {
     const int kv_mul = n_heads / n_kv_heads;
-    if (hd != kSgHd || (kv_mul != 2 && kv_mul != 4) || !env_int("Q3_ATT_SCORES_KV", 1)) return 0;
+    if (hd != kSgHd || (kv_mul != 2 && kv_mul != 4) || !dev_knob("Q3_ATT_SCORES_KV", 1)) return 0;
     return kv_mul;
 }
 struct ScoresShape { int kvm; unsigned gx, gy; size_t smem; };
@@ -300,25 +330,36 @@ static int set_attn_short_smem(const AttnArgs& a) {
     if (!attn_short2_ok(a)) return Q3_OK;
     return set_max_smem((const void*)k_attn_short2<128>, attn_short2_smem_bytes(128, kS2MaxT));
 }
-static void launch_attn_short(const AttnArgs& a, unsigned n_heads, hipStream_t st) {
-    if (attn_short2_ok(a))
-        hipLaunchKernelGGL(k_attn_short2<128>, dim3(n_heads), dim3(kS2Threads), attn_short2_smem_bytes(128, kS2MaxT), st, a);
+static void launch_attn_short(const AttnArgs& a0, unsigned n_heads, hipStream_t st, int row_steps = 0) {
+    AttnArgs a = a0;
+    if (attn_short2_ok(a)) {
+        a.row_steps = row_steps;          // > 0: a position range below 64 -- rows requested at entry, one workgroup per head
+        hipLaunchKernelGGL(k_attn_short2<128>, dim3(n_heads, row_steps > 0 ? 1 : 2), dim3(kS2Threads), attn_short2_smem_bytes(128, kS2MaxT), st, a);
+    }
     else if (a.hd == 128) hipLaunchKernelGGL(k_attn_short<128>, dim3(n_heads), dim3(kWG), 0, st, a);
     else hipLaunchKernelGGL(k_attn_short<64>, dim3(n_heads), dim3(kWG), 0, st, a);
 }
 
 // no_next: the classifier launch without the folded bookkeeping (q3_profile replays launches without advancing the state)
-void launch_one(const Launch& L, q3_engine* e, bool no_next = false) {
+void launch_one(const Launch& L, q3_engine* e, bool no_next = false, int row_steps = 0) {
     if (no_next && L.fam == F_LMHEAD && L.ga.next_cell != nullptr) {
         Launch M = L;
         M.ga.next_cell = nullptr;
         hipLaunchKernelGGL(M.fn, dim3(M.grid), dim3(M.block), M.smem, e->stream, M.ga);
         return;
     }
+#ifdef Q3_DEV
+    if (L.is_kfold) {
+        const int nl = (int)e->plan.size() - 1;
+        hipLaunchKernelGGL(k_kstamp_reduce, dim3((unsigned)nl), dim3(256), 0, e->stream, e->d_kslots, e->d_knslots, e->d_kcells);
+        hipLaunchKernelGGL(k_kstamp_fold, dim3(1), dim3(256), 0, e->stream, e->d_kcells, nl, e->d_kacc);
+        return;
+    }
+#endif
     if (L.is_attn) {
         if (L.attn_kind == 1) launch_attn_scores(L.aa, L.scores_kvm, L.grid, L.grid_y, L.smem, e->stream);
         else if (L.attn_kind == 2) launch_attn_out(L.aa, L.grid, L.grid_y, L.smem, e->stream);
-        else if (L.attn_kind == 3) launch_attn_short(L.aa, L.grid, e->stream);
+        else if (L.attn_kind == 3) launch_attn_short(L.aa, L.grid, e->stream, row_steps);
         else hipLaunchKernelGGL(k_attn, dim3(L.grid), dim3(kWG), L.smem, e->stream, L.aa);
     } else if (L.is_next) {
         hipLaunchKernelGGL(k_next, dim3(1), dim3(kWG), 0, e->stream, e->d_state, e->d_argmax_slots, e->n_argmax_slots,
@@ -353,13 +394,13 @@ GemvShape plan_gemv(int units, int n, int G, bool swiglu, int row_align, int n_c
             if (waste < best_waste) { best_waste = waste; g.JU = ju; }
         }
     }
-    const int force_ju = env_int("Q3_GEMV_JU", 0);
+    const int force_ju = dev_knob("Q3_GEMV_JU", 0);
     if (force_ju >= 1 && force_ju <= 4) g.JU = force_ju;
     const int ru_max = 8 / g.JU, ru_min = swiglu ? 2 : 1;
     const int waves = n_cu * wg_per_cu * kWaves;
     // rows that are a whole number of tiles fold the group terms in registers (k_gemv FIN = 1)
-    if (allow_fin && env_int("Q3_GEMV_FIN", 1) && G == 64 && (nchunks % 4) == 0 &&
-        launch_bytes < ((size_t)env_int("Q3_GEMV_FIN_MAXMB", 1 << 20) << 20)) g.FIN = 1;
+    if (allow_fin && dev_knob("Q3_GEMV_FIN", 1) && G == 64 && (nchunks % 4) == 0 &&
+        launch_bytes < ((size_t)dev_knob("Q3_GEMV_FIN_MAXMB", 1 << 20) << 20)) g.FIN = 1;
     int best_ru = ru_min;
     long best_cost = -1;
     for (int ru = ru_max; ru >= ru_min; ru >>= 1) {
@@ -382,7 +423,7 @@ GemvShape plan_gemv(int units, int n, int G, bool swiglu, int row_align, int n_c
     g.grid = (unsigned)grid;
     // streaming launches (every wave owns at least two tiles): request the second tile before the prologue too
     const long njt_h = (nj + g.JU - 1) / g.JU;
-    if (env_int("Q3_GEMV_PF", 1) && G == 64 && nb * njt_h >= 2 * grid * kWaves && (g.FIN || !allow_fin)) g.PF = 1;
+    if (dev_knob("Q3_GEMV_PF", 1) && G == 64 && nb * njt_h >= 2 * grid * kWaves && (g.FIN || !allow_fin)) g.PF = 1;
     return g;
 }
 
@@ -417,8 +458,14 @@ void q3_engine::release() {
     if (graph_fwd_exec) (void)hipGraphExecDestroy(graph_fwd_exec);
     if (graph_fwd) (void)hipGraphDestroy(graph_fwd);
     if (graph_fwd_long_exec) (void)hipGraphExecDestroy(graph_fwd_long_exec);
+    for (int i = 0; i < kNRange; ++i) {
+        if (graph_rng_exec[i]) (void)hipGraphExecDestroy(graph_rng_exec[i]);
+        if (graph_rng[i]) (void)hipGraphDestroy(graph_rng[i]);
+        if (graph_fwd_rng_exec[i]) (void)hipGraphExecDestroy(graph_fwd_rng_exec[i]);
+        if (graph_fwd_rng[i]) (void)hipGraphDestroy(graph_fwd_rng[i]);
+    }
     if (graph_fwd_long) (void)hipGraphDestroy(graph_fwd_long);
-    void* dptrs[] = {d_next_cell, d_xbq, d_xbs, d_samp_hist, d_samp_counts, d_sampler, d_probs, d_sp, d_keys, d_prompt, d_att_priv, d_argmax_slots, d_stamps, d_blob, d_x, d_q, d_kraw, d_xb, d_hb, d_logits, d_tap, d_key, d_value, d_rope, d_att, d_state, d_out_tokens};
+    void* dptrs[] = {d_kacc, d_kslots, d_kcells, d_knslots, d_next_cell, d_xbq, d_xbs, d_samp_hist, d_samp_counts, d_sampler, d_probs, d_sp, d_keys, d_prompt, d_att_priv, d_argmax_slots, d_stamps, d_blob, d_x, d_q, d_kraw, d_xb, d_hb, d_logits, d_tap, d_key, d_value, d_rope, d_att, d_state, d_out_tokens};
     for (void* p : dptrs)
         if (p) (void)hipFree(p);
     if (h_logits) (void)hipHostFree(h_logits);
@@ -587,11 +634,11 @@ int q3_engine::build_plan() {
     const int dim = cfg.dim, L = cfg.n_layers, hd = cfg.head_dim, V = cfg.vocab_size, H = cfg.hidden_dim;
     const int G = cfg.group_size, ahd = cfg.n_heads * hd, kvd = cfg.n_kv_heads * hd, S = cfg.seq_len;
     const int strict = (flags & Q3_FLAG_FAST) ? 0 : 1;
-    const int small_cap = env_int("Q3_WG_PER_CU_SMALL", 2);   // two workgroups per CU: half the rows (and fold chains) per wave
-    const int big_cap = env_int("Q3_WG_PER_CU_LMHEAD", 2);   // all workgroups resident at once (the NORM prologue keeps ~190 VGPRs live)
-    const int att_lds_max = env_int("Q3_ATT_LDS_MAX", 4096);
+    const int small_cap = dev_knob("Q3_WG_PER_CU_SMALL", 2);   // two workgroups per CU: half the rows (and fold chains) per wave
+    const int big_cap = dev_knob("Q3_WG_PER_CU_LMHEAD", 2);   // all workgroups resident at once (the NORM prologue keeps ~190 VGPRs live)
+    const int att_lds_max = dev_knob("Q3_ATT_LDS_MAX", 4096);
 
-    split_pos = env_int("Q3_ATT_SPLIT_POS", 256);
+    split_pos = dev_knob("Q3_ATT_SPLIT_POS", 256);
     att_stride = (S + 255) & ~255;
     const int slice_w = attn_slice_w(hd, cfg.n_heads, n_cu);
     const int nsl = hd / slice_w;
@@ -599,17 +646,30 @@ int q3_engine::build_plan() {
     cmax_stride = (int)((((size_t)S + 63) / 64 + 63) & ~(size_t)63);
     HIP_TRY(hipMalloc((void**)&d_att, 4 * (size_t)cfg.n_heads * ((size_t)att_stride + cmax_stride)));   // score rows, then their 64-block maxima
     HIP_TRY(hipMalloc((void**)&d_att_priv, 4 * (size_t)cfg.n_heads * nsl * att_stride));
-    if (env_int("Q3_STAMPS", 0)) {
+    kstamps = dev_knob("Q3_KSTAMPS", 0) != 0;
+    if (dev_knob("Q3_STAMPS", 0) || kstamps) {
         HIP_TRY(hipMalloc((void**)&d_stamps, 8 * 16 * (size_t)(5 * L + 4)));
         HIP_TRY(hipMemset(d_stamps, 0, 8 * 16 * (size_t)(5 * L + 4)));
     }
+#ifdef Q3_DEV
+    if (kstamps) {
+        const size_t nl = (size_t)(5 * L + 4);
+        HIP_TRY(hipMalloc((void**)&d_kslots, 16 * (size_t)kKstampSlots * nl));
+        HIP_TRY(hipMemset(d_kslots, 0, 16 * (size_t)kKstampSlots * nl));
+        HIP_TRY(hipMalloc((void**)&d_kcells, 16 * nl));
+        HIP_TRY(hipMalloc((void**)&d_knslots, 4 * nl));
+        HIP_TRY(hipMemset(d_knslots, 0, 4 * nl));
+        HIP_TRY(hipMalloc((void**)&d_kacc, 8 * (2 + 2 * nl)));
+        HIP_TRY(hipMemset(d_kacc, 0, 8 * (2 + 2 * nl)));
+    }
+#endif
 
     auto base_args = [&](int n) {
         GemvArgs a{};
         a.n = n;
         a.group = G;
         a.strict = strict;
-        a.debug = env_int("Q3_ABLATE", 0);
+        a.debug = dev_knob("Q3_ABLATE", 0) | (kstamps ? 64 : 0);
         a.st = d_state;
         a.seq_len = S;
         return a;
@@ -619,7 +679,7 @@ int q3_engine::build_plan() {
     std::vector<Launch> wo_long;       // the long-context plan's Wo launches (k_attn_out emits no quantized operand)
     HIP_TRY(hipMalloc((void**)&d_xbq, (size_t)ahd));
     HIP_TRY(hipMalloc((void**)&d_xbs, 4 * (size_t)(ahd / G)));
-    const int alias0 = env_int("Q3_DEBUG_ALIAS_LAYER0", 0);   // experiment: every layer streams layer 0's weights
+    const int alias0 = dev_knob("Q3_DEBUG_ALIAS_LAYER0", 0);   // experiment: every layer streams layer 0's weights
     for (int l = 0; l < L; ++l) {
         const size_t kv_off = (size_t)l * S * kvd;
         const int lw = alias0 ? 0 : l;
@@ -638,7 +698,7 @@ int q3_engine::build_plan() {
             }
             a.norm_w = rms_att + (size_t)l * dim;
             a.in = d_x;
-            const GemvCfg* cfg = find_cfg(l == 0 ? PRO_EMBED_NORM : PRO_NORM, EPI_QKV, dim, G, env_int("Q3_CFG_QKV", 0));
+            const GemvCfg* cfg = find_cfg(l == 0 ? PRO_EMBED_NORM : PRO_NORM, EPI_QKV, dim, G, dev_knob("Q3_CFG_QKV", 0));
             if (cfg && (hd % cfg->ru) != 0) cfg = nullptr;           // batches must not straddle the q|k|v segments
             if (l == 0) {
                 a.emb_q = tok.q;
@@ -646,7 +706,7 @@ int q3_engine::build_plan() {
                 a.x_out = d_x;
             }
             if (cfg) {
-                a.xfirst = env_int("Q3_XFIRST", (flags & Q3_FLAG_FAST) ? xfirst_dflt(cfg->wgt) : 0);
+                a.xfirst = dev_knob("Q3_XFIRST", (flags & Q3_FLAG_FAST) ? xfirst_dflt(cfg->wgt) : 0);
                 apply_cfg(Ln, a, *cfg, a.total_rows, n_cu);
             } else {
                 const GemvShape gs = plan_gemv(a.total_rows, dim, G, false, hd, n_cu, small_cap);
@@ -659,7 +719,7 @@ int q3_engine::build_plan() {
             Ln.ga = a;
             if (!Ln.fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel instantiated for this tile shape");
             if ((rc = set_max_smem((const void*)Ln.fn, Ln.smem))) return rc;
-            if (d_stamps) { Ln.ga.stamps = d_stamps + 16 * plan.size(); Ln.ga.stamp_block = env_int("Q3_STAMP_BLOCK", 7); }
+            if (d_stamps) { Ln.ga.stamps = kstamps ? d_kslots + 2 * (size_t)kKstampSlots * plan.size() : d_stamps + 16 * plan.size(); Ln.ga.stamp_block = dev_knob("Q3_STAMP_BLOCK", 7); }
             plan.push_back(Ln);
         }
         {   // QK-norm + RoPE + attention                                        layers.rs:346-419
@@ -684,20 +744,20 @@ int q3_engine::build_plan() {
             a.seq_len = S;
             a.strict = strict;
             a.write_q = 0;
-            a.debug = env_int("Q3_ABLATE", 0);
-            a.stamps = d_stamps ? d_stamps + 16 * plan.size() : nullptr;
+            a.debug = dev_knob("Q3_ABLATE", 0) | (kstamps ? 64 : 0);
+            a.stamps = d_stamps ? (kstamps ? d_kslots + 2 * (size_t)kKstampSlots * plan.size() : d_stamps + 16 * plan.size()) : nullptr;
             Ln.aa = a;
             Ln.grid = (unsigned)cfg.n_heads;
             Ln.smem = attn_smem_bytes(hd, use_att_global ? 0 : S);
             if ((rc = set_max_smem((const void*)k_attn, Ln.smem))) return rc;
             // the short plan only ever runs at pos < split_pos
-            if ((hd == 64 || hd == 128) && split_pos <= kShortMaxT && env_int("Q3_ATT_SHORT", 1)) {
+            if ((hd == 64 || hd == 128) && split_pos <= kShortMaxT && dev_knob("Q3_ATT_SHORT", 1)) {
                 Ln.attn_kind = 3;
-                Ln.aa.att_short_form = env_int("Q3_ATT_SHORT", 1) == 2 ? 1 : 0;      // 2: the round 2-4 kernel (A/B)
+                Ln.aa.att_short_form = dev_knob("Q3_ATT_SHORT", 1) == 2 ? 1 : 0;      // 2: the round 2-4 kernel (A/B)
                 if ((rc = set_attn_short_smem(Ln.aa))) return rc;
             }
             // k_attn_short can hand Wo its operand quantized (qwen3.rs:152 fused into the attention epilogue)
-            wo_preq = Ln.attn_kind == 3 ? find_cfg(PRO_PREQR, EPI_RESID, ahd, G, env_int("Q3_CFG_WO", 0)) : nullptr;
+            wo_preq = Ln.attn_kind == 3 ? find_cfg(PRO_PREQR, EPI_RESID, ahd, G, dev_knob("Q3_CFG_WO", 0)) : nullptr;
             if (wo_preq) {
                 Ln.aa.xbq = d_xbq;
                 Ln.aa.xbs = d_xbs;
@@ -717,7 +777,7 @@ int q3_engine::build_plan() {
             // quantize-in-prologue form: the long-context plan always, the short plan when attention emits no int8
             Launch Lq = Ln;
             GemvArgs aq = a;
-            if (const GemvCfg* cq = find_cfg(PRO_QUANT, EPI_RESID, ahd, G, env_int("Q3_CFG_WO_LONG", 0))) {
+            if (const GemvCfg* cq = find_cfg(PRO_QUANT, EPI_RESID, ahd, G, dev_knob("Q3_CFG_WO_LONG", 0))) {
                 apply_cfg(Lq, aq, *cq, dim, n_cu);
             } else {
                 const GemvShape gs = plan_gemv(dim, ahd, G, false, 1, n_cu, small_cap);
@@ -737,7 +797,7 @@ int q3_engine::build_plan() {
             } else {
                 Ln = Lq;
             }
-            if (d_stamps) { Ln.ga.stamps = d_stamps + 16 * plan.size(); Ln.ga.stamp_block = env_int("Q3_STAMP_BLOCK", 7); }
+            if (d_stamps) { Ln.ga.stamps = kstamps ? d_kslots + 2 * (size_t)kKstampSlots * plan.size() : d_stamps + 16 * plan.size(); Ln.ga.stamp_block = dev_knob("Q3_STAMP_BLOCK", 7); }
             plan.push_back(Ln);
         }
         {   // xb = RMSNorm_ffn(x); xq = quantize(xb); hb = silu(W1 xq) * (W3 xq)   qwen3.rs:159-161, layers.rs:468-475
@@ -749,8 +809,8 @@ int q3_engine::build_plan() {
             a.total_rows = 2 * H;
             a.norm_w = rms_ffn + (size_t)l * dim;
             a.in = d_x;
-            if (const GemvCfg* cfg = find_cfg(PRO_NORM, EPI_SWIGLU, dim, G, env_int("Q3_CFG_W13", 0))) {
-                a.xfirst = env_int("Q3_XFIRST_W13", dim < 2048 ? xfirst_dflt(cfg->wgt) : 0);
+            if (const GemvCfg* cfg = find_cfg(PRO_NORM, EPI_SWIGLU, dim, G, dev_knob("Q3_CFG_W13", 0))) {
+                a.xfirst = dev_knob("Q3_XFIRST_W13", dim < 2048 ? xfirst_dflt(cfg->wgt) : 0);
                 apply_cfg(Ln, a, *cfg, H, n_cu);
             } else {
                 const GemvShape gs = plan_gemv(H, dim, G, true, 1, n_cu, small_cap);
@@ -762,7 +822,7 @@ int q3_engine::build_plan() {
             Ln.ga = a;
             if (!Ln.fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel instantiated for this tile shape");
             if ((rc = set_max_smem((const void*)Ln.fn, Ln.smem))) return rc;
-            if (d_stamps) { Ln.ga.stamps = d_stamps + 16 * plan.size(); Ln.ga.stamp_block = env_int("Q3_STAMP_BLOCK", 7); }
+            if (d_stamps) { Ln.ga.stamps = kstamps ? d_kslots + 2 * (size_t)kKstampSlots * plan.size() : d_stamps + 16 * plan.size(); Ln.ga.stamp_block = dev_knob("Q3_STAMP_BLOCK", 7); }
             plan.push_back(Ln);
         }
         {   // hq = quantize(hb); x += W2 hq                                      layers.rs:478-479, qwen3.rs:175
@@ -772,8 +832,8 @@ int q3_engine::build_plan() {
             a.seg[0] = Seg{w2[lw].q, w2[lw].s, d_x, dim, 0};
             a.total_rows = dim;
             a.in = d_hb;
-            if (const GemvCfg* cfg = find_cfg(PRO_QUANT, EPI_RESID, H, G, env_int("Q3_CFG_W2", 0))) {
-                a.xfirst = env_int("Q3_XFIRST_W2", 0);
+            if (const GemvCfg* cfg = find_cfg(PRO_QUANT, EPI_RESID, H, G, dev_knob("Q3_CFG_W2", 0))) {
+                a.xfirst = dev_knob("Q3_XFIRST_W2", 0);
                 apply_cfg(Ln, a, *cfg, dim, n_cu);
             } else {
                 const GemvShape gs = plan_gemv(dim, H, G, false, 1, n_cu, small_cap);
@@ -785,7 +845,7 @@ int q3_engine::build_plan() {
             Ln.ga = a;
             if (!Ln.fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel instantiated for this tile shape");
             if ((rc = set_max_smem((const void*)Ln.fn, Ln.smem))) return rc;
-            if (d_stamps) { Ln.ga.stamps = d_stamps + 16 * plan.size(); Ln.ga.stamp_block = env_int("Q3_STAMP_BLOCK", 7); }
+            if (d_stamps) { Ln.ga.stamps = kstamps ? d_kslots + 2 * (size_t)kKstampSlots * plan.size() : d_stamps + 16 * plan.size(); Ln.ga.stamp_block = dev_knob("Q3_STAMP_BLOCK", 7); }
             plan.push_back(Ln);
         }
     }
@@ -799,9 +859,9 @@ int q3_engine::build_plan() {
         a.in = d_x;
         a.tap_out = d_tap;
         GemvShape gs = plan_gemv(V, dim, G, false, 1, n_cu, big_cap, false);
-        const GemvCfg* lcfg = find_cfg(PRO_NORM, EPI_LOGITS, dim, G, env_int("Q3_CFG_LMHEAD", 1));
+        const GemvCfg* lcfg = find_cfg(PRO_NORM, EPI_LOGITS, dim, G, dev_knob("Q3_CFG_LMHEAD", 0));
         if (lcfg) {
-            a.xfirst = env_int("Q3_XFIRST_LM", 0);
+            a.xfirst = dev_knob("Q3_XFIRST_LM", 0);
             apply_cfg(Ln, a, *lcfg, V, n_cu);
             // streaming launch: cap the grid at the resident set (grid-stride over the row batches)
             const unsigned cap = (unsigned)(n_cu * (lcfg->wgt >= 512 ? 1 : 2));
@@ -812,7 +872,7 @@ int q3_engine::build_plan() {
         HIP_TRY(hipMalloc((void**)&d_argmax_slots, 8 * (size_t)n_argmax_slots));
         HIP_TRY(hipMemset(d_argmax_slots, 0, 8 * (size_t)n_argmax_slots));
         a.argmax_slots = d_argmax_slots;
-        const bool fuse_next = env_int("Q3_FUSE_NEXT", 1) != 0;
+        const bool fuse_next = dev_knob("Q3_FUSE_NEXT", 1) != 0;
         if (fuse_next) {
             HIP_TRY(hipMalloc((void**)&d_next_cell, 16));
             HIP_TRY(hipMemset(d_next_cell, 0, 16));
@@ -830,12 +890,26 @@ int q3_engine::build_plan() {
         Ln.ga = a;
         if (!Ln.fn) return fail(Q3_ERR_UNSUPPORTED, "no kernel instantiated for this tile shape");
         if ((rc = set_max_smem((const void*)Ln.fn, Ln.smem))) return rc;
+        if (d_stamps) { Ln.ga.stamps = kstamps ? d_kslots + 2 * (size_t)kKstampSlots * plan.size() : d_stamps + 16 * plan.size(); Ln.ga.stamp_block = dev_knob("Q3_STAMP_BLOCK", 7); }
         plan.push_back(Ln);
     }
     if (d_next_cell == nullptr) {
         Launch Ln;
         Ln.fam = F_NEXT;
         Ln.is_next = true;
+        plan.push_back(Ln);
+    }
+    if (kstamps) {          // (developer build only: kstamps is false in the product)
+        std::vector<int> ns(plan.size(), 0);
+        for (size_t i = 0; i < plan.size(); ++i) {
+            const bool s2 = plan[i].is_attn && plan[i].attn_kind == 3 && attn_short2_ok(plan[i].aa);
+            const long w = (long)plan[i].grid * (s2 ? 2 : 1) * ((plan[i].is_attn ? (s2 ? kS2Threads : kWG) : (long)plan[i].block) / 64);
+            ns[i] = (int)(w < kKstampSlots ? w : kKstampSlots);
+        }
+        HIP_TRY(hipMemcpy(d_knslots, ns.data(), 4 * ns.size(), hipMemcpyHostToDevice));
+        Launch Ln;
+        Ln.fam = F_NEXT;
+        Ln.is_kfold = true;
         plan.push_back(Ln);
     }
     // long-context plan: every attention launch becomes k_attn_scores (heads x T-chunks) + k_attn_out (heads x slices)
@@ -847,13 +921,13 @@ int q3_engine::build_plan() {
         A.aa.xbq = B.aa.xbq = nullptr;    // the split kernels write f32 xb only; Wo quantizes in its prologue
         A.attn_kind = 1;
         A.aa.stamps = nullptr;            // developer timeline of the long plan: k_attn_out's (Q3_STAMP_SCORES=1: k_attn_scores')
-        if (env_int("Q3_STAMP_SCORES", 0)) { A.aa.stamps = L0.aa.stamps; B.aa.stamps = nullptr; }
+        if (dev_knob("Q3_STAMP_SCORES", 0)) { A.aa.stamps = L0.aa.stamps; B.aa.stamps = nullptr; }
         A.aa.att_global = d_att;
         A.aa.att_stride = att_stride;
         A.aa.q_out = nullptr;
         const ScoresShape ss = scores_shape(hd, A.aa.n_heads, A.aa.n_kv_heads, S);
         A.scores_kvm = ss.kvm;
-        A.aa.att_cmax = B.aa.att_cmax = (ss.kvm && env_int("Q3_ATT_CMAX", 1)) ? d_att + (size_t)A.aa.n_heads * att_stride : nullptr;
+        A.aa.att_cmax = B.aa.att_cmax = (ss.kvm && dev_knob("Q3_ATT_CMAX", 1)) ? d_att + (size_t)A.aa.n_heads * att_stride : nullptr;
         A.aa.cmax_stride = B.aa.cmax_stride = cmax_stride;
         A.grid = ss.gx;
         A.grid_y = ss.gy;
@@ -882,14 +956,34 @@ int q3_engine::capture() {
     for (const Launch& L : plan_long) launch_one(L, this);
     HIP_TRY(hipStreamEndCapture(stream, &graph_long));
     HIP_TRY(hipGraphInstantiate(&graph_long_exec, graph_long, nullptr, nullptr, 0));
-    if (env_int("Q3_FWD_GRAPH", 1)) {
+    // position ranges: only where the short plan runs k_attn_short2 (head_dim 128, cache a whole number of 8-row steps)
+    for (const Launch& L : plan)
+        if (L.is_attn && L.attn_kind == 3 && attn_short2_ok(L.aa)) ranges = dev_knob("Q3_ATT_RANGES", 0) != 0 && dev_knob("Q3_FWD_LOGITS_HOST", 0) == 0;
+    if (ranges)
+        for (int i = 0; i < kNRange; ++i) {
+            HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            for (const Launch& L : plan) launch_one(L, this, false, kRangeSteps[i]);
+            HIP_TRY(hipStreamEndCapture(stream, &graph_rng[i]));
+            HIP_TRY(hipGraphInstantiate(&graph_rng_exec[i], graph_rng[i], nullptr, nullptr, 0));
+        }
+    if (dev_knob("Q3_FWD_GRAPH", 1)) {
         const size_t lbytes = 4 * (size_t)cfg.vocab_size;
+        if (ranges)
+            for (int i = 0; i < kNRange; ++i) {
+                HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+                HIP_TRY(hipMemcpyAsync(d_state, h_state, sizeof(State), hipMemcpyHostToDevice, stream));
+                for (const Launch& L : plan) launch_one(L, this, false, kRangeSteps[i]);
+                HIP_TRY(hipMemcpyAsync(h_logits, d_logits, lbytes, hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamEndCapture(stream, &graph_fwd_rng[i]));
+                HIP_TRY(hipGraphInstantiate(&graph_fwd_rng_exec[i], graph_fwd_rng[i], nullptr, nullptr, 0));
+            }
         for (int lng = 0; lng < 2; ++lng) {
             HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
             HIP_TRY(hipMemcpyAsync(d_state, h_state, sizeof(State), hipMemcpyHostToDevice, stream));
+            // (developer build, forward-only experiment: d_logits is NOT filled, so device-side sampling after q3_forward is undefined)
             // Q3_FWD_LOGITS_HOST=1: the classifier stores its logits straight into the pinned host buffer (device-visible,
             // fine-grained) and the download node disappears (SURVEY section 7 "Logits egress"; measured in DESIGN section 7)
-            const bool host_out = env_int("Q3_FWD_LOGITS_HOST", 0) != 0;
+            const bool host_out = dev_knob("Q3_FWD_LOGITS_HOST", 0) != 0;
             for (const Launch& L : (lng ? plan_long : plan)) {
                 if (host_out && L.fam == F_LMHEAD && !L.is_attn && !L.is_next) {
                     Launch M = L;
@@ -908,10 +1002,17 @@ int q3_engine::capture() {
 // draw = false: logits only (q3_forward: the caller samples, the device sampler must not consume a coin)
 int q3_engine::enqueue_forward(bool eager, size_t pos, bool draw) {
     const bool lng = (int64_t)pos >= (int64_t)split_pos;
+    const int rng = lng ? -1 : range_of(pos);
     if (graph_exec && !eager) {
-        HIP_TRY(hipGraphLaunch(lng ? graph_long_exec : graph_exec, stream));
+        HIP_TRY(hipGraphLaunch(lng ? graph_long_exec : (rng >= 0 ? graph_rng_exec[rng] : graph_exec), stream));
     } else {
-        for (const Launch& L : (lng ? plan_long : plan)) launch_one(L, this);
+        // (eager launches: the same row-request hint the captured range graphs carry, as long as the engine keeps range graphs at
+        // all -- an engine without a captured graph decides from the position alone)
+        int steps = 0;
+        if (!lng && (ranges || !graph_exec))
+            for (int i = kNRange - 1; i >= 0; --i)
+                if (pos < (size_t)(8 * kRangeSteps[i])) steps = kRangeSteps[i];
+        for (const Launch& L : (lng ? plan_long : plan)) launch_one(L, this, false, steps);
         HIP_TRY(hipGetLastError());
     }
     return draw ? enqueue_sample() : Q3_OK;
@@ -1023,7 +1124,8 @@ const float* q3_forward(q3_engine* e, size_t token, size_t pos) {
         e->h_state->step = 0;
         e->h_state->prompt_len = 0;
         e->h_state->argmax = 0ull;
-        hipError_t ge = hipGraphLaunch((int64_t)pos >= (int64_t)e->split_pos ? e->graph_fwd_long_exec : e->graph_fwd_exec, e->stream);
+        const int rng = (int64_t)pos >= (int64_t)e->split_pos ? -1 : e->range_of(pos);
+        hipError_t ge = hipGraphLaunch((int64_t)pos >= (int64_t)e->split_pos ? e->graph_fwd_long_exec : (rng >= 0 && e->graph_fwd_rng_exec[rng] ? e->graph_fwd_rng_exec[rng] : e->graph_fwd_exec), e->stream);
         if (ge == hipSuccess) ge = hipStreamSynchronize(e->stream);
         if (ge != hipSuccess) {
             fail(Q3_ERR_HIP, "forward failed: %s", hipGetErrorString(ge));
@@ -1083,7 +1185,7 @@ int q3_generate_greedy(q3_engine* e, size_t first_token, size_t first_pos, size_
     HIP_TRY(hipMemcpyAsync(e->h_tokens, e->d_out_tokens, 4 * n_tokens, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     clock_gettime(CLOCK_MONOTONIC, &t2);
-    if (e->d_stamps) {
+    if (e->d_stamps && !e->kstamps) {
         const size_t nl = e->plan.size();
         std::vector<unsigned long long> h(16 * nl);
         HIP_TRY(hipMemcpy(h.data(), e->d_stamps, 8 * 16 * nl, hipMemcpyDeviceToHost));
@@ -1105,6 +1207,36 @@ int q3_generate_greedy(q3_engine* e, size_t first_token, size_t first_pos, size_
         }
         if (cnt[F_ATTN]) fprintf(stderr, "[q3 stamps] attn: issued %.0f  norm %.0f  staged %.0f  scores %.0f  softmax %.0f  vsum %.0f\n", acc[F_ATTN][1] / cnt[F_ATTN], acc[F_ATTN][2] / cnt[F_ATTN], acc[F_ATTN][3] / cnt[F_ATTN], acc[F_ATTN][4] / cnt[F_ATTN], acc[F_ATTN][5] / cnt[F_ATTN], acc[F_ATTN][6] / cnt[F_ATTN]);
     }
+#ifdef Q3_DEV
+    if (e->kstamps && e->d_kacc) {
+        // per family: average duration of a launch (first wave in .. last wave out) and average gap to its predecessor's end,
+        // both from the in-kernel 100 MHz clock, averaged over every token folded so far; the sum over a token against the
+        // host's wall clock for this call
+        const size_t nl = e->plan.size() - 1;
+        std::vector<unsigned long long> h(2 + 2 * nl);
+        HIP_TRY(hipMemcpy(h.data(), e->d_kacc, 8 * h.size(), hipMemcpyDeviceToHost));
+        const double ntok = (double)h[0];
+        double dur[F_COUNT] = {}, gap[F_COUNT] = {}; int cnt[F_COUNT] = {};
+        double tot = 0.0;
+        for (size_t i = 0; i < nl; ++i) {
+            const int f = e->plan[i].fam;
+            dur[f] += (double)h[2 + 2 * i] * 0.01 / ntok;      // 10 ns ticks -> us
+            gap[f] += (double)h[3 + 2 * i] * 0.01 / ntok;
+            cnt[f]++;
+            tot += ((double)h[2 + 2 * i] + (double)h[3 + 2 * i]) * 0.01 / ntok;
+        }
+        const double wall_us = ((t2.tv_sec - t0.tv_sec) * 1e6 + (t2.tv_nsec - t0.tv_nsec) * 1e-3) / (double)n_tokens;
+        fprintf(stderr, "[q3 kstamps] {\"tokens_folded\": %.0f, \"sum_duration_plus_gap_us_per_token\": %.2f, \"wall_us_per_token_this_call\": %.2f, \"families\": {", ntok, tot, wall_us);
+        bool first = true;
+        for (int f = 0; f < F_COUNT; ++f)
+            if (cnt[f] && f != F_NEXT) {
+                fprintf(stderr, "%s\"%s\": {\"launches_per_token\": %d, \"avg_duration_us\": %.3f, \"avg_gap_to_predecessor_us\": %.3f}", first ? "" : ", ",
+                        kFamilyNames[f], cnt[f], dur[f] / cnt[f], gap[f] / cnt[f]);
+                first = false;
+            }
+        fprintf(stderr, "}}\n");
+    }
+#endif
     if (getenv("Q3_DEBUG_TIMING"))
         fprintf(stderr, "[q3] generate_greedy n=%zu enqueue %.1f us, drain %.1f us\n", n_tokens,
                 (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3,
@@ -1174,8 +1306,8 @@ int q3_sampler_set(q3_engine* e, float temperature, float topp, uint64_t rng_see
     a.st = e->d_state;
     a.out_tokens = e->d_out_tokens;
     a.out_cap = e->out_cap;
-    a.pre_exp = env_int("Q3_SAMPLER_PRE_EXP", 1);
-    a.phase = (a.pre_exp && env_int("Q3_SAMPLER_PIPELINE", 1)) ? 1 : 0;
+    a.pre_exp = dev_knob("Q3_SAMPLER_PRE_EXP", 1);
+    a.phase = (a.pre_exp && dev_knob("Q3_SAMPLER_PIPELINE", 1)) ? 1 : 0;
     a.hist = e->d_samp_hist;
     a.counts = e->d_samp_counts;
     a.stamps = e->d_stamps ? e->d_stamps + 16 * (size_t)(5 * e->cfg.n_layers + 3) : nullptr;
@@ -1591,7 +1723,7 @@ int q3_op_attention(float* xb, float* q, float* key_cache_layer, const float* va
         const ScoresShape ss = scores_shape((int)head_dim, (int)n_heads, (int)n_kv_heads, (int)seq_len);
         if ((rc = set_attn_scores_smem(ss)) || (rc = set_attn_out_smem(sm2))) return rc;
         DevBuf dcmax;
-        if (ss.kvm && env_int("Q3_ATT_CMAX", 1)) {               // 64-timestep block maxima, as in the engine's long plan
+        if (ss.kvm && dev_knob("Q3_ATT_CMAX", 1)) {               // 64-timestep block maxima, as in the engine's long plan
             a.cmax_stride = (int)(((seq_len + 63) / 64 + 63) & ~(size_t)63);
             if ((rc = dcmax.alloc(4 * n_heads * (size_t)a.cmax_stride))) return rc;
             a.att_cmax = dcmax.as<float>();
@@ -1600,8 +1732,8 @@ int q3_op_attention(float* xb, float* q, float* key_cache_layer, const float* va
         launch_attn_out(a, (unsigned)n_heads, (unsigned)nsl, sm2, 0);
         if ((rc = op_end())) return rc;
         HIP_TRY(hipMemcpy(dq.p, dqout.p, 4 * ahd, hipMemcpyDeviceToDevice));
-    } else if ((head_dim == 64 || head_dim == 128) && env_int("Q3_ATT_SHORT", 1)) {
-        a.att_short_form = env_int("Q3_ATT_SHORT", 1) == 2 ? 1 : 0;
+    } else if ((head_dim == 64 || head_dim == 128) && dev_knob("Q3_ATT_SHORT", 1)) {
+        a.att_short_form = dev_knob("Q3_ATT_SHORT", 1) == 2 ? 1 : 0;
         if ((rc = set_attn_short_smem(a))) return rc;
         launch_attn_short(a, (unsigned)n_heads, 0);
     } else {

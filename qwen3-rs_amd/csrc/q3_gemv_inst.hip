@@ -1,8 +1,7 @@
 // q3_gemv_inst.hip -- every instantiation of k_gemv the planner can select, in a translation unit of its own so that
 // the library builds in parallel (make -j).  q3_engine.hip reaches the kernels only through gemv_pick() / find_cfg().
 #include <hip/hip_runtime.h>
-#define Q3_GEMV_ONLY
-#include "q3_kernels.h"
+#include "q3_gemv.h"
 
 using namespace q3;
 typedef void (*GemvFn)(const GemvArgs);
@@ -66,43 +65,60 @@ namespace {
 #define Q3_CFG(PRO, EPI, N, WGT, EPT, RU, JU, PF) \
     {PRO, EPI, N, WGT, EPT, RU, JU, PF, (GemvFn)k_gemv<PRO, EPI, 4, RU, JU, 1, PF, N, WGT, EPT>}
 #define Q3_CFG_NORM_QKV(N, WGT, EPT, RU, JU, PF) Q3_CFG(PRO_NORM, EPI_QKV, N, WGT, EPT, RU, JU, PF), Q3_CFG(PRO_EMBED_NORM, EPI_QKV, N, WGT, EPT, RU, JU, PF)
+// The first entry of a role is what the product runs.  The other candidates of a role (the forms that lost their A/B; they stay
+// selectable through Q3_CFG_<FAMILY>=k for re-sweeps) exist in the developer build only: Q3_ALT(...).
+#ifdef Q3_DEV
+#define Q3_ALT(...) __VA_ARGS__,
+#else
+#define Q3_ALT(...)
+#endif
 const GemvCfg kGemvCfgs[] = {
     // --- QKV: RMSNorm_att + quantize + wq|wk|wv
     // (dim 1024, end of r03: the 512-thread / two-rows-per-wave forms lead the 1024-thread ones by 0.1 us per launch since the
     // wave-0 block loads go through LDS; same-process A/B of the three 0.6B changes below: 1,552-1,567 -> 1,582-1,599 tok/s)
-    Q3_CFG_NORM_QKV(1024, 512, 2, 2, 1, 0), Q3_CFG_NORM_QKV(1024, 1024, 1, 1, 1, 0), Q3_CFG_NORM_QKV(1024, 1024, 4, 1, 1, 0),
-    Q3_CFG_NORM_QKV(1024, 256, 4, 2, 1, 0),
+    Q3_CFG_NORM_QKV(1024, 512, 2, 2, 1, 0),
+    Q3_ALT(Q3_CFG_NORM_QKV(1024, 1024, 1, 1, 1, 0), Q3_CFG_NORM_QKV(1024, 1024, 4, 1, 1, 0), Q3_CFG_NORM_QKV(1024, 256, 4, 2, 1, 0))
     // (r04 sweep, 4B: 12 waves x 2 rows = 6,144 rows exactly, 6.18 vs 6.56 us; the same form at 4096 is slower, 8.33 vs 7.94 us)
     Q3_CFG_NORM_QKV(2560, 768, 4, 2, 3, 0),
-    Q3_CFG_NORM_QKV(2560, 1024, 4, 1, 3, 0), Q3_CFG_NORM_QKV(2560, 1024, 4, 1, 3, 1), Q3_CFG_NORM_QKV(2560, 1024, 4, 2, 3, 0),
-    Q3_CFG_NORM_QKV(4096, 1024, 4, 1, 4, 0), Q3_CFG_NORM_QKV(4096, 1024, 4, 1, 4, 1), Q3_CFG_NORM_QKV(4096, 1024, 4, 2, 4, 0),
+    Q3_ALT(Q3_CFG_NORM_QKV(2560, 1024, 4, 1, 3, 0), Q3_CFG_NORM_QKV(2560, 1024, 4, 1, 3, 1), Q3_CFG_NORM_QKV(2560, 1024, 4, 2, 3, 0))
+    Q3_CFG_NORM_QKV(4096, 1024, 4, 1, 4, 0),
     // (r04) 12-wave workgroups: 6,144 rows = 3,072 waves x 2 rows, every byte of the launch requested at kernel entry
-    Q3_CFG_NORM_QKV(4096, 768, 4, 2, 4, 0),
+    Q3_ALT(Q3_CFG_NORM_QKV(4096, 1024, 4, 1, 4, 1), Q3_CFG_NORM_QKV(4096, 1024, 4, 2, 4, 0), Q3_CFG_NORM_QKV(4096, 768, 4, 2, 4, 0))
     // --- W1|W3 + SwiGLU
-    Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 512, 2, 4, 1, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 1024, 1, 2, 1, 0),
-    Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 1024, 4, 2, 1, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 256, 4, 4, 1, 0),
-    Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 1024, 4, 2, 3, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 512, 4, 2, 3, 1),
-    Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 512, 4, 2, 3, 0),
-    Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 1024, 4, 2, 4, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 512, 4, 2, 4, 1),
-    Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 512, 4, 2, 4, 0),
+    Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 512, 2, 4, 1, 0),
+    Q3_ALT(Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 1024, 1, 2, 1, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 1024, 4, 2, 1, 0),
+           Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 256, 4, 4, 1, 0))
+    Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 1024, 4, 2, 3, 0),
+    Q3_ALT(Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 512, 4, 2, 3, 1), Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 512, 4, 2, 3, 0))
+    Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 1024, 4, 2, 4, 0),
+    Q3_ALT(Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 512, 4, 2, 4, 1), Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 512, 4, 2, 4, 0))
     // (r04: a 12-wave PF = 1 form still spills 92 B at 4096 and ran at 30.4 us; 2560: 16.5 vs 12.6 us -- not kept)
     // --- Wo behind the short-context attention kernel (xb arrives quantized): register-direct activation
-    Q3_CFG(PRO_PREQR, EPI_RESID, 2048, 256, 4, 1, 2, 0), Q3_CFG(PRO_PREQR, EPI_RESID, 2048, 512, 4, 1, 2, 0),
-    Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 256, 4, 1, 4, 0), Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 256, 4, 2, 4, 0),
-    Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 512, 4, 1, 4, 0), Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 1024, 4, 1, 4, 0),
+    Q3_CFG(PRO_PREQR, EPI_RESID, 2048, 256, 4, 1, 2, 0),
+    Q3_ALT(Q3_CFG(PRO_PREQR, EPI_RESID, 2048, 512, 4, 1, 2, 0))
+    Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 256, 4, 1, 4, 0),
+    Q3_ALT(Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 256, 4, 2, 4, 0), Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 512, 4, 1, 4, 0),
+           Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 1024, 4, 1, 4, 0))
     // --- quantize + W2 (and Wo of the long-context plan)
-    Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 256, 4, 1, 3, 0), Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 512, 4, 1, 3, 0),
-    Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 1024, 4, 1, 3, 0),
-    Q3_CFG(PRO_QUANT, EPI_RESID, 9728, 1024, 4, 1, 2, 1), Q3_CFG(PRO_QUANT, EPI_RESID, 9728, 512, 4, 1, 2, 1),
-    Q3_CFG(PRO_QUANT, EPI_RESID, 12288, 1024, 4, 1, 4, 1), Q3_CFG(PRO_QUANT, EPI_RESID, 12288, 512, 4, 1, 4, 1),
+    Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 256, 4, 1, 3, 0),
+    Q3_ALT(Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 512, 4, 1, 3, 0), Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 1024, 4, 1, 3, 0))
+    Q3_CFG(PRO_QUANT, EPI_RESID, 9728, 1024, 4, 1, 2, 1),
+    Q3_ALT(Q3_CFG(PRO_QUANT, EPI_RESID, 9728, 512, 4, 1, 2, 1))
+    Q3_CFG(PRO_QUANT, EPI_RESID, 12288, 1024, 4, 1, 4, 1),
+    Q3_ALT(Q3_CFG(PRO_QUANT, EPI_RESID, 12288, 512, 4, 1, 4, 1))
     // (r04: the whole 12 KiB row of a wave requested before the prologue, two 6 KiB tiles: 13.3 vs 11.8 us; 9728 as 2 x 5 KiB: 9.2
     // vs 8.3 us -- request depth at entry is not what these launches wait for)
-    Q3_CFG(PRO_QUANT, EPI_RESID, 2048, 512, 4, 1, 2, 0), Q3_CFG(PRO_QUANT, EPI_RESID, 2048, 256, 4, 1, 2, 0),
-    Q3_CFG(PRO_QUANT, EPI_RESID, 4096, 1024, 4, 1, 4, 0), Q3_CFG(PRO_QUANT, EPI_RESID, 4096, 512, 4, 1, 4, 0),
+    Q3_CFG(PRO_QUANT, EPI_RESID, 2048, 512, 4, 1, 2, 0),
+    Q3_ALT(Q3_CFG(PRO_QUANT, EPI_RESID, 2048, 256, 4, 1, 2, 0))
+    Q3_CFG(PRO_QUANT, EPI_RESID, 4096, 1024, 4, 1, 4, 0),
+    Q3_ALT(Q3_CFG(PRO_QUANT, EPI_RESID, 4096, 512, 4, 1, 4, 0))
     // --- final RMSNorm + classifier (streaming: two tiles requested before the prologue)
-    Q3_CFG(PRO_NORM, EPI_LOGITS, 1024, 256, 4, 8, 1, 1), Q3_CFG(PRO_NORM, EPI_LOGITS, 1024, 512, 4, 8, 1, 1),
-    Q3_CFG(PRO_NORM, EPI_LOGITS, 2560, 256, 4, 2, 3, 1), Q3_CFG(PRO_NORM, EPI_LOGITS, 2560, 512, 4, 2, 3, 1),
-    Q3_CFG(PRO_NORM, EPI_LOGITS, 4096, 256, 4, 2, 4, 1), Q3_CFG(PRO_NORM, EPI_LOGITS, 4096, 512, 4, 2, 4, 1),
+    Q3_CFG(PRO_NORM, EPI_LOGITS, 1024, 512, 4, 8, 1, 1),
+    Q3_ALT(Q3_CFG(PRO_NORM, EPI_LOGITS, 1024, 256, 4, 8, 1, 1))
+    Q3_CFG(PRO_NORM, EPI_LOGITS, 2560, 512, 4, 2, 3, 1),
+    Q3_ALT(Q3_CFG(PRO_NORM, EPI_LOGITS, 2560, 256, 4, 2, 3, 1))
+    Q3_CFG(PRO_NORM, EPI_LOGITS, 4096, 512, 4, 2, 4, 1),
+    Q3_ALT(Q3_CFG(PRO_NORM, EPI_LOGITS, 4096, 256, 4, 2, 4, 1))
 };
 }  // namespace
 

@@ -26,6 +26,13 @@ def _emit(tok: Tokenizer, token: int):
     sys.stdout.flush()
 
 
+def _out(raw: bytes):
+    """(everything on stdout goes through the byte layer: decoded tokens are raw bytes, and mixing them with the text layer's
+    own buffer reorders the output when stdout is a pipe)"""
+    sys.stdout.buffer.write(raw)
+    sys.stdout.flush()
+
+
 def run_generate(t, tok: Tokenizer, prompt: str) -> int:
     """generation.rs:9-48"""
     prompt_tokens = tok.encode(prompt or "")
@@ -68,36 +75,46 @@ def _prefill(t, ids, pos) -> int:
 
 
 def run_chat(t, tok: Tokenizer, cli_prompt, system_prompt) -> int:
-    """generation.rs:50-151"""
+    """generation.rs:50-151, loop for loop: when the window is exhausted the position goes back to 0 and a user turn begins
+    (generation.rs:65-69) -- the KV cache is NOT cleared, rows are simply rewritten from the front, and with a `-i` prompt
+    the prompt is fed again exactly as the reference does (get_user_input, generation.rs:174-188)."""
     seq_len = t.get_config().seq_len
-    pos = 0
-    while pos < seq_len:
-        if pos == 0 and cli_prompt is not None:
-            user = cli_prompt
-        elif cli_prompt is not None:
-            break
-        else:
-            sys.stdout.write("> ")
-            sys.stdout.flush()
-            line = sys.stdin.readline()
-            user = line.strip()
-            if not line or not user:
+    pos, user_turn, nxt = 0, True, 0
+    n_gen, t0 = 0, None
+    while True:
+        if pos >= seq_len:                                 # "Reset context if window exceeded"
+            pos, user_turn = 0, True
+            _out(b"\n")
+        if user_turn:
+            _report(n_gen, t0)
+            n_gen, t0 = 0, None
+            if pos == 0 and cli_prompt is not None:
+                user = cli_prompt
+            elif cli_prompt is not None:
+                user = ""
+            else:
+                _out(b"> ")
+                user = sys.stdin.readline().strip()
+            if not user and not (pos == 0 and cli_prompt is not None):
                 break
-        ids = tok.encode(tok.render_prompt(pos, system_prompt, user))[: max(seq_len - pos, 0)]
-        if not ids:
-            break
-        nxt = _prefill(t, ids, pos)
-        pos += len(ids)
-        n_gen, t0 = 0, None
-        while pos < seq_len and nxt not in (tok.bos_token_id, tok.eos_token_id):
+            ids = tok.encode(tok.render_prompt(pos, system_prompt, user))[: max(seq_len - pos, 0)]
+            if ids:
+                nxt = _prefill(t, ids, pos)
+                pos += len(ids)
+            user_turn = False
+        else:
+            if nxt in (tok.bos_token_id, tok.eos_token_id):
+                _report(n_gen, t0)
+                n_gen, t0 = 0, None
+                _out(b"\n")
+                user_turn = True
+                continue
             if t0 is None:
                 t0 = time.perf_counter()
             _emit(tok, nxt)
             nxt = t.forward_argmax(nxt, pos)
             n_gen += 1
             pos += 1
-        _report(n_gen, t0)
-        print()
     return 0
 
 

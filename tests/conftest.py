@@ -63,6 +63,36 @@ def q3():
     return qwen3_rs_amd
 
 
+_PRODUCT_ENV = {"Q3_PREFILL_M", "Q3_DEBUG_TIMING"}       # what libqwen3_hip.so reads (include/qwen3_hip.h, "Environment")
+
+
+@pytest.fixture
+def dev_forms(q3, monkeypatch):
+    """Kernel-form switches live in the developer build only (libqwen3_hip_dev.so, -DQ3_DEV).  `dev_forms({"Q3_X": "1"})` sets the
+    variables and, if any of them is not one the product library reads, makes the rest of the test create its engines from the
+    developer build (same sources, same results -- which is what these tests assert for every form)."""
+    import subprocess
+    stack = []
+
+    def apply(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        if any(k not in _PRODUCT_ENV for k in env) and not stack:
+            path = q3.dev_lib_path()
+            if "Q3_HIP_LIB" not in os.environ:
+                subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "qwen3-rs_amd"), "dev"])
+            ctx = q3.use_library(path)
+            lib = ctx.__enter__()
+            stack.append(ctx)
+            have = lib.q3_build_id().decode()
+            if "Q3_HIP_LIB" not in os.environ and have != q3.source_build_id():
+                raise RuntimeError(f"{path}: build id {have}, sources hash to {q3.source_build_id()}")
+
+    yield apply
+    while stack:
+        stack.pop().__exit__(None, None, None)
+
+
 @pytest.fixture(scope="session")
 def tmp_ckpt_dir(tmp_path_factory):
     return str(tmp_path_factory.mktemp("q3ckpt"))

@@ -547,7 +547,7 @@ def test_batched_prefill_is_sequential_equivalent(q3, shape_name, n_prompt, firs
 
 @pytest.mark.parametrize("shape_name", ["small-longctx", "qwen3-0.6b-dims-l2"])      # head_dim 64 (k_attn_gqa) / 128 (k_attn_pf)
 @pytest.mark.parametrize("block", [32, 48, 128, 256, -128, -256, 512, -512])
-def test_batched_prefill_block_sizes_agree(q3, block, shape_name, tmp_path_factory, monkeypatch):
+def test_batched_prefill_block_sizes_agree(q3, block, shape_name, tmp_path_factory, monkeypatch, dev_forms):
     """Q3_PREFILL_M picks the positions per weight pass: 32 = the batch-32 kernels (k_bgemm + LDS term tile), larger blocks
     the dense kernels (k_pgemm in-lane fold, k_attn_pf).  Every block size must give the cache rows and tokens of the
     sequential prompt loop (generation.rs:116-123) bit for bit, including a ragged last block and a non-zero start.
@@ -555,12 +555,11 @@ def test_batched_prefill_block_sizes_agree(q3, block, shape_name, tmp_path_facto
     negative block: the same size with its other forms -- -128: 2 row tiles per workgroup (Q3_PGEMM2_RT=2), -256: 4 x 8 tiles
     (Q3_PGEMM2_PT=8), -512: 8 x 8 tiles (Q3_PGEMM3_RT=8); 48 positions (3 tiles) stay on k_pgemm."""
     if block == -128:
-        monkeypatch.setenv("Q3_PGEMM2_RT", "2")
+        dev_forms({"Q3_PGEMM2_RT": "2"})
     if block == -256:
-        monkeypatch.setenv("Q3_PGEMM2_PT", "8")
+        dev_forms({"Q3_PGEMM2_PT": "8"})
     if block == -512:                                   # 8 x 8 workgroup tiles (k_pgemm3<.., 8, 8, 1>)
-        monkeypatch.setenv("Q3_PGEMM2_PT", "8")
-        monkeypatch.setenv("Q3_PGEMM3_RT", "8")
+        dev_forms({"Q3_PGEMM2_PT": "8", "Q3_PGEMM3_RT": "8"})
     block = abs(block)
     ck = q3.checkpoint
     shape = ck.SHAPES[shape_name]
@@ -637,13 +636,12 @@ _DGEMM_FORMS = [{}, {"Q3_DGEMM_FAMILIES": "15"}, {"Q3_DGEMM_FAMILIES": "15", "Q3
 
 
 @pytest.mark.parametrize("form", range(len(_DGEMM_FORMS)))
-def test_batched_decode_8b_layer_dims_vs_forward_and_oracle(q3, oracle, form, monkeypatch):
+def test_batched_decode_8b_layer_dims_vs_forward_and_oracle(q3, oracle, form, dev_forms):
     """BASELINE config 4's matrix shapes on the batched path: row lengths 4096 / 12288 (64 and 192 groups per row), 32
     heads over 8 kv heads, untied classifier -- 2 layers, reduced vocabulary.  32 streams x 8 steps: every stream's
     logits bit-identical to q3_forward on the same (token, pos) sequence for the first 4 streams, and 2 streams
     against the oracle.  Run for every matmul form of the batched path (_DGEMM_FORMS)."""
-    for k, v in _DGEMM_FORMS[form].items():
-        monkeypatch.setenv(k, v)
+    dev_forms(_DGEMM_FORMS[form])
     ck = q3.checkpoint
     name = "qwen3-8b-dims-l2"
     shape = ck.SHAPES[name]
@@ -682,12 +680,11 @@ def test_batched_decode_8b_layer_dims_vs_forward_and_oracle(q3, oracle, form, mo
 
 
 @pytest.mark.parametrize("form", [0, 1, 2, 6])
-def test_batched_decode_4b_layer_dims_vs_forward(q3, form, monkeypatch):
+def test_batched_decode_4b_layer_dims_vs_forward(q3, form, dev_forms):
     """The 4B matrix shapes on the batched path: row lengths 2560 / 9728 are 40 / 152 quantization groups -- not a multiple of
     16, so k_dgemm runs its 8-group ring (and k_bgemm ragged phases) -- 20 streams (a ragged second stream tile), 6 steps: logits
     of four streams bit-identical to q3_forward.  Forms as in _DGEMM_FORMS (default, every family in-lane at both depths, k_bgemm)."""
-    for k, v in _DGEMM_FORMS[form].items():
-        monkeypatch.setenv(k, v)
+    dev_forms(_DGEMM_FORMS[form])
     ck = q3.checkpoint
     name = "qwen3-4b-dims-l2"
     shape = ck.SHAPES[name]
@@ -1043,11 +1040,12 @@ def test_device_sampler_large_vocab_and_prefill(q3, oracle, tmp_path_factory):
 
 @pytest.mark.parametrize("shape_name", ["qwen3-4b-dims-l2", "tiny-g64"])      # vocabulary 16,384 / 512 (one partial workgroup range)
 @pytest.mark.parametrize("pipeline", ["1", "0"])
-def test_device_sampler_pipelined_and_single_kernel_forms_agree(q3, oracle, pipeline, shape_name, tmp_path_factory, monkeypatch):
+def test_device_sampler_pipelined_and_single_kernel_forms_agree(q3, oracle, pipeline, shape_name, tmp_path_factory, dev_forms):
     """The engine's draw runs as a pipeline (exact sum | chip-wide normalise + histogram + compaction | sort + exact walks) or,
     with Q3_SAMPLER_PIPELINE=0, as the single-workgroup kernel the batched sampler and q3_op_sample use: both must give the
     oracle's tokens (sampler.rs:118-139), for a flat-ish and a peaked temperature, nucleus and plain multinomial."""
-    monkeypatch.setenv("Q3_SAMPLER_PIPELINE", pipeline)
+    if pipeline != "1":
+        dev_forms({"Q3_SAMPLER_PIPELINE": pipeline})
     ck = q3.checkpoint
     shape = ck.SHAPES[shape_name]
     path = str(tmp_path_factory.mktemp("samp2") / "m.bin")
@@ -1069,10 +1067,10 @@ def test_device_sampler_pipelined_and_single_kernel_forms_agree(q3, oracle, pipe
             assert got == want, f"T {temperature} top-p {topp} pipeline {pipeline}"
 
 
-def test_dense_prefill_with_the_batched_attention_kernel(q3, tmp_path_factory, monkeypatch):
+def test_dense_prefill_with_the_batched_attention_kernel(q3, tmp_path_factory, dev_forms):
     """Q3_PREFILL_ATT_PF=0 keeps the dense matmuls but runs the block's attention on k_attn_gqa2 (the fallback for layouts
     k_attn_pf2 does not cover): same cache rows and tokens as the sequential prompt loop."""
-    monkeypatch.setenv("Q3_PREFILL_ATT_PF", "0")
+    dev_forms({"Q3_PREFILL_ATT_PF": "0"})
     ck = q3.checkpoint
     shape = ck.SHAPES["qwen3-0.6b-dims-l2"]
     path = str(tmp_path_factory.mktemp("pf0") / "m.bin")

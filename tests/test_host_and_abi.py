@@ -62,6 +62,18 @@ def test_product_never_touches_the_oracle():
     subprocess.check_call([sys.executable, "-c", code])
 
 
+def test_product_library_reads_only_the_documented_environment_variables(q3):
+    """include/qwen3_hip.h ("Environment") lists what libqwen3_hip.so reads; every other Q3_* switch lives in the developer build
+    (-DQ3_DEV).  The binary's strings must be exactly that list (at most 8 names), and no developer symbol may be exported."""
+    header = open(os.path.join(ROOT, "include", "qwen3_hip.h")).read()
+    env_doc = header[header.index(" * Environment:"):header.index("#ifndef QWEN3_HIP_H")]
+    documented = set(re.findall(r"^ \*     (Q3_[A-Z0-9_]+)", env_doc, re.M))
+    assert 0 < len(documented) <= 8, documented
+    blob = open(q3.lib_path(), "rb").read()
+    found = set(m.decode() for m in re.findall(rb"(?<![A-Za-z0-9_])(Q3_[A-Z][A-Z0-9_]+)\x00", blob))
+    assert found == documented, (sorted(found), sorted(documented))
+
+
 class _Recorder:
     """A fake Transformer recording the (token,pos) calls it receives."""
 
@@ -265,3 +277,21 @@ def test_host_sample_argmax_last_maximum_under_total_order(q3):
             assert got == want, (a[:8], got, want)
             assert np.array_equal(dst.view(np.int32), a.view(np.int32))
         assert lib.q3_host_sample_argmax(a.ctypes.data_as(fp), a.size, None) == want
+
+
+@pytest.mark.gpu
+def test_bench_two_real_replicas_on_two_devices():
+    """`bench.py --gpus 2` with REAL engines: one process + one engine per GPU (devices 0 and 1), no collective on the data
+    path, value = sum of tokens / max time.  Needs two visible GPUs (the 1-GPU test boxes skip it)."""
+    import torch
+    if torch.cuda.device_count() < 2:          # (counting devices does not initialise HIP in this process)
+        pytest.skip("fewer than two GPUs visible")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "2", "--no-cpu-baseline",
+           "--no-other-configs"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 16 and d["scaling"] == "weak"
+    one = subprocess.run(cmd[:3] + ["1"] + cmd[4:], capture_output=True, text=True, timeout=1200)
+    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["value"] > 1.5 * d1["value"], (d["value"], d1["value"])      # two independent replicas: ~2x, never ~1x

@@ -184,21 +184,62 @@ def test_cli_inference_generate_and_chat_match_the_reference_loops(q3, oracle, t
             token, pos = nxt, pos + 1
         return out
 
-    def ref_chat(prompt, temperature, topp, seed):
-        om = oracle.OracleModel(path, 40)
+    def ref_chat(lines, temperature, topp, seed, ctx, cli_prompt=None, max_turns=8):
+        """generation.rs:50-151 driven by the oracle: stdout as the reference prints it (interactive: "> " before every read,
+        a newline when the window wraps or a turn ends), positions wrap to 0 without clearing the cache (generation.rs:65-69)."""
+        om = oracle.OracleModel(path, ctx)
         smp = oracle.Sampler(shape.vocab_size, temperature, topp, seed)
-        ids, pos, nxt, out = tok.encode(tok.render_prompt(0, None, prompt)), 0, 0, b""
-        for t in ids:
-            nxt = smp.sample(om.forward(t, pos)); pos += 1
-        while pos < 40 and nxt not in (tok.bos_token_id, tok.eos_token_id):
-            out += tok.decode_bytes(nxt)
-            nxt = smp.sample(om.forward(nxt, pos)); pos += 1
+        lines = list(lines)
+        pos, user_turn, nxt, out, turns = 0, True, 0, b"", 0
+        while True:
+            if pos >= ctx:
+                pos, user_turn = 0, True
+                out += b"\n"
+            if user_turn:
+                if pos == 0 and cli_prompt is not None:
+                    user = cli_prompt
+                elif cli_prompt is not None:
+                    user = ""
+                else:
+                    out += b"> "
+                    user = lines.pop(0).strip() if lines else ""
+                if not user and not (pos == 0 and cli_prompt is not None):
+                    break
+                turns += 1
+                if turns > max_turns:
+                    break
+                for t in tok.encode(tok.render_prompt(pos, None, user)):
+                    if pos >= ctx:
+                        break
+                    nxt = smp.sample(om.forward(t, pos)); pos += 1
+                user_turn = False
+            else:
+                if nxt in (tok.bos_token_id, tok.eos_token_id):
+                    out += b"\n"
+                    user_turn = True
+                    continue
+                out += tok.decode_bytes(nxt)
+                nxt = smp.sample(om.forward(nxt, pos)); pos += 1
         return out
 
-    for mode, ref in (("generate", ref_generate), ("chat", ref_chat)):
-        for temperature, topp in ((0.0, 0.9), (0.9, 0.8)):
-            r = subprocess.run([sys.executable, "-m", "qwen3_rs_amd.cli", "inference", path, "-m", mode, "-i", "hello world",
-                                "-t", str(temperature), "-p", str(topp), "-s", "77", "-c", "40"], env=env, capture_output=True, timeout=600)
-            assert r.returncode == 0, r.stderr.decode(errors="replace")
-            want = ref("hello world", temperature, topp, 77)
-            assert r.stdout.rstrip(b"\n") == want.rstrip(b"\n") or r.stdout.startswith(want), (mode, temperature, r.stdout, want)
+    cli = [sys.executable, "-m", "qwen3_rs_amd.cli", "inference", path]
+    for temperature, topp in ((0.0, 0.9), (0.9, 0.8)):
+        r = subprocess.run(cli + ["-m", "generate", "-i", "hello world", "-t", str(temperature), "-p", str(topp), "-s", "77", "-c", "40"],
+                           env=env, capture_output=True, timeout=600)
+        assert r.returncode == 0, r.stderr.decode(errors="replace")
+        want = ref_generate("hello world", temperature, topp, 77)
+        assert r.stdout.rstrip(b"\n") == want.rstrip(b"\n") or r.stdout.startswith(want), ("generate", temperature, r.stdout, want)
+        # chat, interactive: one turn that runs into the end of a 40-position window, then end of input
+        r = subprocess.run(cli + ["-m", "chat", "-t", str(temperature), "-p", str(topp), "-s", "77", "-c", "40"],
+                           env=env, capture_output=True, timeout=600, input=b"hello world\n")
+        assert r.returncode == 0, r.stderr.decode(errors="replace")
+        assert r.stdout == ref_chat(["hello world"], temperature, topp, 77, 40), ("chat", temperature, r.stdout)
+    # context wrap-around (generation.rs:65-69): a 24-position window, two user turns, ~40 generated tokens; the second turn
+    # starts again at position 0 on top of the first turn's rows (nothing is cleared), then the input ends
+    for temperature in (0.0, 0.9):
+        r = subprocess.run(cli + ["-m", "chat", "-t", str(temperature), "-p", "0.8", "-s", "5", "-c", "24"],
+                           env=env, capture_output=True, timeout=600, input=b"hello world\nhello again world\n")
+        assert r.returncode == 0, r.stderr.decode(errors="replace")
+        want = ref_chat(["hello world", "hello again world"], temperature, 0.8, 5, 24)
+        assert want.count(b"> ") == 3 and len(want) > 30
+        assert r.stdout == want, ("chat wrap", temperature, r.stdout, want)

@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
     auto launch = [&](int which) {
         const AttnArgs a = args(which);
         if (which == 0) hipLaunchKernelGGL(k_attn_short<128>, dim3(n_heads), dim3(kWG), 0, s, a);
-        else hipLaunchKernelGGL(k_attn_short2<128>, dim3(n_heads), dim3(kS2Threads), smem2, s, a);
+        else hipLaunchKernelGGL(k_attn_short2<128>, dim3(n_heads, getenv("NOVSPLIT") ? 1 : 2), dim3(kS2Threads), smem2, s, a);
     };
     int bad_total = 0;
     for (int pos : {0, 1, 7, 8, 9, 16, 17, 31, 32, 33, 63, 64, 65, 70, 100, 127, 128, 129, 135, 160, 161, 200, 255}) {
