@@ -1,0 +1,6 @@
+#!/bin/bash
+D=qwen3-rs_amd/libqwen3_hip_dev.so
+for abl in 0 256 512 768; do
+  echo "ablate $abl: $(Q3_HIP_LIB=$D Q3_ABLATE=$abl python3 tools/longctx_prof.py qwen3-4b 2300 16 2>/dev/null | head -3 | tr '\n' ' ')"
+done
+Q3_STAMPS=1 Q3_HIP_LIB=$D Q3_CTX=4096 python3 tools/stamps_at.py 2300 qwen3-4b 2>&1 | grep "stamps\] attn" | tail -3
