@@ -1112,7 +1112,9 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
                 // clamped to the cache, not to the context: rows past the current position are allocated memory whose
                 // contents are masked at commit time, and the address then does not wait for the position
                 const int t = min(c0 + r0 + u * rps, a.seq_len - 1);
-                R.v[u] = *(const v4f*)(vbase + (size_t)t * kvd + 4 * c4);
+                // (developer ablation 1024, timing only: the slice's rows read as if they were stored back to back)
+                R.v[u] = Q3_DEV_ABLATE(a, 1024) ? *(const v4f*)(a.value_cache + ((size_t)((blockIdx.x & 7) * gridDim.y + blockIdx.y) * a.seq_len + t) * w + 4 * c4)
+                                                : *(const v4f*)(vbase + (size_t)t * kvd + 4 * c4);
             }
         }
     };
@@ -1344,11 +1346,10 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
     if (2 * K < np) v_issue(vra, 2 * K);
     __syncthreads();
     if (w0_folds && a.strict && wave == 0) {
-        // The chain wave (reference order, slices of 8 / 16): one uninterrupted stream of adds over all chunks.  It meets the
-        // staging waves' per-chunk barrier 16 timesteps before the end of its chunk -- every read of the current tile has
-        // been issued by then, and the staging waves, a whole chunk ahead, are already waiting there -- and uses the last
-        // 16 adds to bring in the head of the next tile, so no LDS latency and no barrier sits between two chunks.
-        // (Lanes >= w run along on the last row and are dropped at the store: the barrier stays outside divergent code.)
+        // The chain wave (reference order, slices of 8 / 16): one uninterrupted stream of adds over all chunks.  It never meets a
+        // barrier: 64 timesteps before the end of its chunk it reads the staging waves' arrival count (behind its last burst of
+        // reads), publishes "tile consumed", and brings in the head of the next tile under the chunk's last 32 adds.
+        // (Lanes >= w run along on the last row and are dropped at the store.)
         const int row = min(tid, w - 1);
         // (round 5: s_setprio 3 for this wave -- it shares its SIMD with three staging waves -- measured, no change: 905.8 vs 905.4 us
         // of attention per token at position 2,300 on the 4B dims; the staging waves do not take the chain's issue slots)
