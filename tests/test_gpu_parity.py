@@ -184,6 +184,35 @@ def test_attention(ops, oracle, nh, nkv, hd, S, pos):
     assert np.max(np.abs(xb - rb)) <= FAST_TOL and np.max(np.abs(q2 - rq)) <= FAST_TOL
 
 
+@pytest.mark.parametrize("nh,nkv,S,pos", [
+    (16, 8, 256, 0), (16, 8, 256, 7), (16, 8, 256, 8), (16, 8, 256, 23), (16, 8, 256, 63), (16, 8, 256, 64), (16, 8, 256, 65),
+    (16, 8, 256, 95), (16, 8, 256, 129), (16, 8, 256, 191), (16, 8, 256, 192), (16, 8, 256, 255),
+    (32, 8, 136, 100),             # four query heads per kv head
+    (8, 8, 72, 70),                # one query head per kv head
+    (16, 8, 8, 7),                 # the smallest cache k_attn_short2 takes (one 8-row step)
+    (16, 8, 100, 99), (16, 8, 20, 17),   # caches that are not a whole number of 8-row steps: k_attn_short
+])
+def test_attention_short_contexts_head_dim_128(ops, oracle, nh, nkv, S, pos):
+    """k_attn_short2 (round 5: coalesced key / value staging, q*K product tile, one or two workgroups per head) across its
+    internal switch points -- staging tiers (8-row steps), one / two / four score waves (64 / 128 / 256 positions), value rows
+    through LDS (<= 64 positions) or straight to the output waves, the second workgroup per head past 64 positions -- and the
+    hand-back to k_attn_short for caches it does not take.  Bit for bit against the oracle (layers.rs:346-419), stale rows
+    beyond the context included in the cache."""
+    hd = 128
+    rng = np.random.default_rng(1000 * S + pos)
+    kvd = nkv * hd
+    q = (3.0 * rng.standard_normal(nh * hd)).astype(np.float32)
+    K = rng.standard_normal((S, kvd)).astype(np.float32)          # rows past pos keep stale values: they must not matter
+    V = rng.standard_normal((S, kvd)).astype(np.float32)
+    qw = (1 + 0.1 * rng.standard_normal(hd)).astype(np.float32)
+    kw = (1 + 0.1 * rng.standard_normal(hd)).astype(np.float32)
+    rb, rq, rk = oracle.attention(q, K, V, qw, kw, pos, nh, nkv, hd)
+    xb, q2, k2 = ops.attention(q, K, V, qw, kw, pos, nh, nkv, hd, strict=True)
+    assert_biteq(xb, rb, "xb")
+    assert_biteq(q2, rq, "q after norm+rope")
+    assert_biteq(k2.reshape(S, kvd)[pos], rk.reshape(S, kvd)[pos], "K row written in place")
+
+
 @pytest.mark.parametrize("nh,nkv,hd,S,pos", [
     (4, 2, 64, 4600, 4500),        # head_dim 64: per-query-head scores kernel, block-wide row maximum
     (8, 2, 128, 4600, 4500),       # 4 query heads per kv head: shared K chunks, 71 block maxima (more than one per lane)
