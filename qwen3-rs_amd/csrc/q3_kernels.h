@@ -1060,9 +1060,6 @@ template <int W_T, bool P_LDS>
 // (developer timeline, Q3_DEV builds: 1 loads issued, 2 scores in registers, 3 max, 4 exps written, 5 exact sum, 6 end)
 __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    // chain wave <-> staging waves (reference order, slices of 8 / 16): [0] tiles committed x staging waves, [1] tiles consumed
-    __shared__ unsigned ao_sync[2];
-    if (threadIdx.x == 0) { ao_sync[0] = 0u; ao_sync[1] = 0u; }       // (published by the softmax's barriers)
     ATT_STAMP(0);
     const int hd = a.hd;
     const int w = W_T ? W_T : a.slice_w;                 // slice width (power of two >= 8, or hd)
@@ -1346,10 +1343,10 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
     if (2 * K < np) v_issue(vra, 2 * K);
     __syncthreads();
     if (w0_folds && a.strict && wave == 0) {
-        // The chain wave (reference order, slices of 8 / 16): one uninterrupted stream of adds over all chunks.  It never meets a
-        // barrier: 64 timesteps before the end of its chunk it reads the staging waves' arrival count (behind its last burst of
-        // reads), publishes "tile consumed", and brings in the head of the next tile under the chunk's last 32 adds.
-        // (Lanes >= w run along on the last row and are dropped at the store.)
+        // The chain wave (reference order, slices of 8 / 16): one uninterrupted stream of adds over all chunks.  It meets the
+        // staging waves' per-chunk barrier 32 timesteps before the end of its chunk -- every read of the current tile has
+        // been issued by then -- and uses the last 32 adds to bring in the head of the next tile.
+        // (Lanes >= w run along on the last row and are dropped at the store: the barrier stays outside divergent code.)
         const int row = min(tid, w - 1);
         // (round 5: s_setprio 3 for this wave -- it shares its SIMD with three staging waves -- measured, no change: 905.8 vs 905.4 us
         // of attention per token at position 2,300 on the 4B dims; the staging waves do not take the chain's issue slots)
@@ -1394,45 +1391,21 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             {
-                // the chunk's last 64 timesteps.  No barrier with the staging waves (round 5: a __syncthreads here drains this wave's
-                // LDS queue and cost the chain ~450 cycles per 256-timestep chunk, 1.7 us per launch at 2,300 positions): the arrival
-                // count of the next tile rides in behind this burst of reads, the "tile consumed" word goes out behind them (DS
-                // operations of a wave execute in order, so a staging wave that SEES it overwrites nothing still to be read).
+                // the chunk's last 64 timesteps meet the staging waves' barrier.  (Round 5 tried LDS counters instead -- arrival count of
+                // the next tile read behind the last burst, "tile consumed" stored behind it: bit-identical in most runs, 906 -> 902 us
+                // of attention per token at position 2,300, but 4 runs in 10 of the 33-chunk operator test returned a wrong 8-element
+                // slice, with or without a compiler barrier around the store.  The barrier stays; what the chain really waits for is
+                // the staging waves' value rows)
 #pragma unroll
-                for (int u = 0; u < 8; ++u) bv[u] = vr[q + 8 + u];
-                unsigned got = __hip_atomic_load(&ao_sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store(&ao_sync[1], (unsigned)(c0 / K) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) fold4(av[u]);
+                for (int u = 0; u < 8; ++u) { bv[u] = vr[q + 8 + u]; fold4(av[u]); }
+                if (!Q3_DEV_ABLATE(a, 256)) __syncthreads();     // the staging waves' barrier of this chunk: tile c+1 is complete
                 if (c0 + K < np) {
-                    const unsigned need = (unsigned)(kAoWaves - 1) * ((unsigned)(c0 / K) + 1u);     // tile c0/K + 1 complete
-                    while (got < need) {
-                        __builtin_amdgcn_s_sleep(1);
-                        got = __hip_atomic_load(&ao_sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
                     for (int u = 0; u < 8; ++u) av[u] = vn[u];
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) fold4(bv[u]);
             }
-        }
-    } else if (w0_folds && a.strict) {
-        // the staging waves of that form: tile k goes into buffer k & 1 once the chain wave has consumed tile k - 2, and is counted in
-        auto commit_tile = [&](VRegs& R, int k) {
-            if (k >= 2) {
-                while (__hip_atomic_load(&ao_sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)(k - 1)) __builtin_amdgcn_s_sleep(2);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            }
-            v_commit(R, k * K, k & 1);
-            if ((k + 2) * K < np) v_issue(R, (k + 2) * K);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) __hip_atomic_fetch_add(&ao_sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        };
-        for (int k = 1; k * K < np; k += 2) {
-            commit_tile(vrb, k);
-            if ((k + 1) * K < np) commit_tile(vra, k + 1);
         }
     } else
     for (int c0 = 0; c0 < np; c0 += 2 * K) {
