@@ -66,11 +66,14 @@ __global__ __launch_bounds__(kS2Threads) void k_attn_short2(const AttnArgs a) {
     Q3_PIN_S(a.q_norm_w); Q3_PIN_S(a.k_norm_w); Q3_PIN_S(a.rope); Q3_PIN_S(a.xb); Q3_PIN_S(a.n_heads); Q3_PIN_S(a.n_kv_heads);
     Q3_PIN_S(a.write_q);
 
-    const int h = blockIdx.x;
+    // workgroup -> head: the hardware deals workgroups round-robin over the 8 XCDs (linear id % 8), each with its own L2.  The query
+    // heads of one kv head read the same key / value rows, so they take block indices that are equal modulo n_kv_heads (8 for every
+    // listed model): the rows cross the fabric into ONE L2 and the other workgroups of the group hit there.
+    const int kv_mul = a.n_heads / a.n_kv_heads;
+    const int kvh = (int)blockIdx.x % a.n_kv_heads;
+    const int h = kvh * kv_mul + (int)blockIdx.x / a.n_kv_heads;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kv_mul = a.n_heads / a.n_kv_heads;
-    const int kvh = h / kv_mul;
     const size_t kvd = (size_t)a.n_kv_heads * HD;
     // the position is requested first by every role and turned into a scalar as late as the role allows
     const int pos_v = a.pos_override >= 0 ? a.pos_override : a.st->pos;

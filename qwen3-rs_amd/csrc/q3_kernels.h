@@ -1069,9 +1069,12 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
     float* opart = red + 64;                             // [kAoWaves][w]
     float* p_lds = opart + kAoWaves * w;                   // [npad] when the row fits (see attn_out_smem_bytes)
 
-    const int h = blockIdx.x, sl = blockIdx.y, nsl = gridDim.y;
+    // workgroup -> head: every slice of every query head of one kv head on the same XCD (block indices equal modulo n_kv_heads, see
+    // k_attn_short2): the kv head's value rows enter ONE L2 instead of up to eight
+    const int sl = blockIdx.y, nsl = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kv_mul = a.n_heads / a.n_kv_heads, kvh = h / kv_mul;
+    const int kv_mul = a.n_heads / a.n_kv_heads, kvh = (int)blockIdx.x % a.n_kv_heads;
+    const int h = kvh * kv_mul + (int)blockIdx.x / a.n_kv_heads;
     const size_t kvd = (size_t)a.n_kv_heads * hd;
     const float* src = a.att_global + (size_t)h * a.att_stride;
     const int npad_max = (a.seq_len + 255) & ~255;
