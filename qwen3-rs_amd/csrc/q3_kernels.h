@@ -914,7 +914,21 @@ __global__ __launch_bounds__(kWG) void k_attn_scores_kv(const AttnArgs a) {
     const int kvh = blockIdx.x, c = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t kvd = (size_t)a.n_kv_heads * hd;
-    const int pos = __builtin_amdgcn_readfirstlane(a.pos_override >= 0 ? a.pos_override : a.st->pos);
+    // The position is requested first; the raw q / k values do not depend on it and go out BEHIND it, before it is waited for
+    // (round 5: a readfirstlane right here put the position's whole round trip in front of every other load of the launch; the raw
+    // k row is read by every chunk's workgroup now -- one cache line -- and used by the one that holds the position).
+    const int pos_v = a.pos_override >= 0 ? a.pos_override : a.st->pos;
+    float rv[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int idx = tid + u * kWG;                 // (KVM_T + 1) * 128 <= 640 values: raw q of each head, then raw k
+        if (idx < KVM_T * hd) rv[u] = a.q[(size_t)kvh * KVM_T * hd + idx];
+        else if (idx < (KVM_T + 1) * hd) rv[u] = a.k_raw[(size_t)kvh * hd + idx - KVM_T * hd];
+    }
+    float rv2 = 0.f;
+    if (KVM_T == 4 && tid < hd) rv2 = a.k_raw[(size_t)kvh * hd + tid];
+    __builtin_amdgcn_sched_barrier(0);
+    const int pos = __builtin_amdgcn_readfirstlane(pos_v);       // the oldest load: a counted wait
     const int np = pos + 1;
     const int t0 = c * TCH;
     if (t0 >= np) return;
@@ -924,15 +938,6 @@ __global__ __launch_bounds__(kWG) void k_attn_scores_kv(const AttnArgs a) {
     // the wave that normalises the new K row: the first one without a query head, or wave 0 after its own head
     constexpr int kwave = KVM_T < kWaves ? KVM_T : 0;
 
-    float rv[2] = {0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int idx = tid + u * kWG;                 // (KVM_T + 1) * 128 <= 640 values: raw q of each head, then raw k
-        if (idx < KVM_T * hd) rv[u] = a.q[(size_t)kvh * KVM_T * hd + idx];
-        else if (idx < (KVM_T + 1) * hd && has_pos) rv[u] = a.k_raw[(size_t)kvh * hd + idx - KVM_T * hd];
-    }
-    float rv2 = 0.f;
-    if (KVM_T == 4 && tid < hd && has_pos) rv2 = a.k_raw[(size_t)kvh * hd + tid];
     RopeRegs rr, rrk;
     rope_regs_load(rr, wave < KVM_T ? a.q_norm_w : a.k_norm_w, cs, hd);
     rrk = rr;
