@@ -80,7 +80,13 @@ def dev_forms(q3, monkeypatch):
         if any(k not in _PRODUCT_ENV for k in env) and not stack:
             path = q3.dev_lib_path()
             if "Q3_HIP_LIB" not in os.environ:
-                subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "qwen3-rs_amd"), "dev"])
+                # the prebuilt developer library travels with the snapshot like the product library: it is used as it is when its
+                # build id matches the sources (no object directory exists on a fresh box, `make` would recompile everything)
+                code = ("import ctypes,sys\ntry:\n L=ctypes.CDLL(sys.argv[1]); L.q3_build_id.restype=ctypes.c_char_p; print(L.q3_build_id().decode())\n"
+                        "except Exception as e: print('unreadable')")
+                have = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True).stdout.strip() if os.path.exists(path) else None
+                if have != q3.source_build_id():
+                    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "qwen3-rs_amd"), "dev"])
             ctx = q3.use_library(path)
             lib = ctx.__enter__()
             stack.append(ctx)
