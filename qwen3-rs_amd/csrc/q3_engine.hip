@@ -200,6 +200,7 @@ struct q3_engine {
     std::vector<QT> wq, wk, wv, wo, w1, w2, w3;
     float *d_x = nullptr, *d_q = nullptr, *d_kraw = nullptr, *d_xb = nullptr, *d_hb = nullptr, *d_logits = nullptr;
     float *d_tap = nullptr, *d_key = nullptr, *d_value = nullptr, *d_rope = nullptr, *d_att = nullptr;
+    float* d_value_t = nullptr;                // transposed copy of the value cache, [L][kv_dim][seq_len]: what k_attn_out streams (long contexts)
     int8_t* d_xbq = nullptr;                   // attention output quantized by k_attn_short (operand of the PRO_PREQR Wo launch)
     float* d_xbs = nullptr;
     State* d_state = nullptr;
@@ -465,7 +466,7 @@ void q3_engine::release() {
         if (graph_fwd_rng[i]) (void)hipGraphDestroy(graph_fwd_rng[i]);
     }
     if (graph_fwd_long) (void)hipGraphDestroy(graph_fwd_long);
-    void* dptrs[] = {d_kacc, d_kslots, d_kcells, d_knslots, d_next_cell, d_xbq, d_xbs, d_samp_hist, d_samp_counts, d_sampler, d_probs, d_sp, d_keys, d_prompt, d_att_priv, d_argmax_slots, d_stamps, d_blob, d_x, d_q, d_kraw, d_xb, d_hb, d_logits, d_tap, d_key, d_value, d_rope, d_att, d_state, d_out_tokens};
+    void* dptrs[] = {d_value_t, d_kacc, d_kslots, d_kcells, d_knslots, d_next_cell, d_xbq, d_xbs, d_samp_hist, d_samp_counts, d_sampler, d_probs, d_sp, d_keys, d_prompt, d_att_priv, d_argmax_slots, d_stamps, d_blob, d_x, d_q, d_kraw, d_xb, d_hb, d_logits, d_tap, d_key, d_value, d_rope, d_att, d_state, d_out_tokens};
     for (void* p : dptrs)
         if (p) (void)hipFree(p);
     if (h_logits) (void)hipHostFree(h_logits);
@@ -599,6 +600,11 @@ int q3_engine::load(const char* path, uint32_t ctx_len) {
     HIP_TRY(hipMalloc((void**)&d_value, 4 * kv_elems));
     HIP_TRY(hipMemset(d_key, 0, 4 * kv_elems));
     HIP_TRY(hipMemset(d_value, 0, 4 * kv_elems));
+    // the long-context plan streams a transposed copy of the value rows (k_attn_out; contexts that can reach the split position only)
+    if ((S % 4) == 0 && S > dev_knob("Q3_ATT_SPLIT_POS", 256) && dev_knob("Q3_VALUE_T", 1)) {
+        HIP_TRY(hipMalloc((void**)&d_value_t, 4 * kv_elems));
+        HIP_TRY(hipMemset(d_value_t, 0, 4 * kv_elems));
+    }
     HIP_TRY(hipMemset(d_x, 0, 4 * dim));
     HIP_TRY(hipMalloc((void**)&d_state, sizeof(State)));
     HIP_TRY(hipMemset(d_state, 0, sizeof(State)));
@@ -690,6 +696,7 @@ int q3_engine::build_plan() {
             a.seg[0] = Seg{wq[lw].q, wq[lw].s, d_q, ahd, 0};
             a.seg[1] = Seg{wk[lw].q, wk[lw].s, d_kraw, kvd, 0};
             a.seg[2] = Seg{wv[lw].q, wv[lw].s, d_value + kv_off, kvd, kvd};
+            a.v_t = d_value_t ? d_value_t + kv_off : nullptr;
             a.total_rows = ahd + 2 * kvd;
             for (int k = 0; k < 2; ++k) {
                 a.qkv_dw[k] = (const char*)a.seg[k + 1].wq - (const char*)a.seg[k].wq;
@@ -731,6 +738,7 @@ int q3_engine::build_plan() {
             a.key_cache = d_key + kv_off;
             a.k_raw = d_kraw;
             a.value_cache = d_value + kv_off;
+            a.value_t = d_value_t ? d_value_t + kv_off : nullptr;
             a.q_norm_w = q_ln + (size_t)l * hd;
             a.k_norm_w = k_ln + (size_t)l * hd;
             a.rope = d_rope;
@@ -1339,6 +1347,7 @@ int q3_reset_kv(q3_engine* e) {
     const size_t bytes = 4 * (size_t)e->cfg.n_layers * e->cfg.seq_len * e->cfg.n_kv_heads * e->cfg.head_dim;
     HIP_TRY(hipMemsetAsync(e->d_key, 0, bytes, e->stream));
     HIP_TRY(hipMemsetAsync(e->d_value, 0, bytes, e->stream));
+    if (e->d_value_t) HIP_TRY(hipMemsetAsync(e->d_value_t, 0, bytes, e->stream));
     // the classifier's {argmax cell, ticket} pair is self-clearing per token; a reset also recovers it after a launch that
     // did not run to completion
     if (e->d_next_cell) HIP_TRY(hipMemsetAsync(e->d_next_cell, 0, 16, e->stream));
@@ -1714,6 +1723,14 @@ int q3_op_attention(float* xb, float* q, float* key_cache_layer, const float* va
     a.strict = (flags & Q3_FLAG_FAST) ? 0 : 1;
     a.write_q = 1;
     a.stamps = nullptr;
+    DevBuf dvt;
+    if (split && (seq_len % 4) == 0) {
+        // the engine's long-context plan streams a transposed copy of the value rows: the operator builds it the same way
+        if ((rc = dvt.alloc(4 * seq_len * kvd))) return rc;
+        hipLaunchKernelGGL(k_value_transpose, dim3((unsigned)((kvd + 63) / 64), (unsigned)((seq_len + 63) / 64), 1u), dim3(kWG), 0, 0,
+                           (const float*)dv.p, dvt.as<float>(), (int)seq_len, (int)kvd, 0, (int)seq_len);
+        a.value_t = dvt.as<float>();
+    }
     if (split) {
         a.att_stride = att_stride;
         a.att_priv = dpriv.as<float>();

@@ -254,6 +254,10 @@ struct GemvArgs {
     // weights only after wave 0 holds its block of x -- otherwise x queues behind tens of MB of weight requests of the other
     // workgroups and the exact sum starts ~3.5 us late (r03 stamps, 8B QKV: x after 8,955 cycles)
     int xfirst;
+    // EPI_QKV: transposed copy of this layer's value cache, [kv_dim][seq_len] (nullptr: none).  The long-context output kernel walks
+    // 16-element slices of the value rows over thousands of timesteps: in the row-major cache that is a 64-byte piece every 4 KB,
+    // here a contiguous run per element.  The value row of the current position is written to both.
+    float* v_t;
 };
 
 // LDS layout of the GEMV kernels (dynamic shared memory, 16-byte aligned carve):
@@ -1310,6 +1314,7 @@ __global__ __launch_bounds__(WGT) void k_gemv(const GemvArgs a) {
                 rs.out[lane] = acc;
             } else if (EPI == EPI_QKV) {
                 rs.out[(size_t)pos * rs.ops + lane] = acc;    // V rows go straight into the cache row of this position
+                if (rs.ops != 0 && a.v_t != nullptr) a.v_t[(size_t)(rs.row0 + lane) * a.seq_len + pos] = acc;     // ... and into its transposed copy
             } else if (EPI == EPI_RESID) {
                 rs.out[lane] = rs.resid + acc;          // ResidualConnection::forward, layers.rs:249-259
             } else if (EPI == EPI_SWIGLU) {

@@ -98,6 +98,7 @@ struct AttnArgs {
     int n_pos;                // k_attn_pf2 (dense prefill): positions in the block
     int att_short_form;       // host bookkeeping: 1 = keep k_attn_short where k_attn_short2 is eligible (A/B)
     int row_steps;            // k_attn_short2: > 0 = 8-row steps of K / V to request at kernel entry (the graph of a position range < 64)
+    const float* value_t;     // k_attn_out: transposed value cache of this layer, [kv_dim][seq_len] (nullptr: stage from value_cache)
 };
 
 // LDS plan of k_attn (floats): q_s[hd] k_s[hd] raw[2hd] sq[2hd] opart[kWaves*hd] red[64] att[att_lds]
@@ -1109,8 +1110,26 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
     VRegs vra, vrb;
     // every_wave: the two requests in front of the softmax are made by wave 0 as well (it discards them) -- loads behind
     // a branch make hipcc's wait for the scores conservative, i.e. a wait for the V rows
+    // reference order with a transposed value cache: a staging thread owns 4 consecutive timesteps of one element (float4 q of element e:
+    // K / 4 float4 per element and chunk), the chunk of an element is one contiguous run of K floats
+    const bool vtr = a.value_t != nullptr && a.strict != 0;              // wave-uniform
+    const float* vtbase = vtr ? a.value_t + ((size_t)kvh * hd + (size_t)sl * w) * (size_t)a.seq_len : nullptr;
+    constexpr int KQ = kVChunk / 4;
+    const int npass_t = (w * KQ + nst - 1) / nst;                        // 1 / 2 / 2 for slice widths 8 / 16 / 32
     auto v_issue = [&](VRegs& R, int c0, bool every_wave = false) {
         if (!every_wave && !stager) return;
+        if (vtr) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (u < npass_t) {
+                    const int idx = min(sid + u * nst, w * KQ - 1);
+                    const int e = idx / KQ, tq = idx % KQ;
+                    const int t = min(c0 + 4 * tq, a.seq_len - 4);      // clamped to the cache (seq_len % 4 == 0: host)
+                    R.v[u] = *(const v4f*)(vtbase + (size_t)e * a.seq_len + t);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (u < npass) {                             // (compile-time for the instantiated slice widths)
@@ -1270,6 +1289,25 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
         if (!stager || Q3_DEV_ABLATE(a, 512)) return;
         float* vbuf = vbuf0 + buf * (kVChunk + kVPad) * w;
         float* pbuf = pbuf0 + buf * kVChunk;
+        if (vtr) {
+            // products p[t] * v[t][e] of four consecutive timesteps: one b128 read of the probabilities, one b128 write of the tile
+            // row (the row-major cache needs four scattered b32 writes per float4)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = sid + u * nst;
+                if (u < npass_t && idx < w * KQ) {
+                    const int e = idx / KQ, tq = idx % KQ;
+                    const int t = c0 + 4 * tq;                           // < npad: chunks start below np and npad is a multiple of 256
+                    const v4f pe = *(const v4f*)(p + t);
+                    const v4f vv = R.v[u];
+                    v4f x;
+                    x.x = (pe.x * inv) * vv.x; x.y = (pe.y * inv) * vv.y; x.z = (pe.z * inv) * vv.z; x.w = (pe.w * inv) * vv.w;
+                    x.x = t + 0 < np ? x.x : 0.0f; x.y = t + 1 < np ? x.y : 0.0f; x.z = t + 2 < np ? x.z : 0.0f; x.w = t + 3 < np ? x.w : 0.0f;
+                    *(v4f*)(vbuf + e * (kVChunk + kVPad) + 4 * tq) = x;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int r = r0 + u * rps;
@@ -1486,6 +1524,23 @@ __global__ __launch_bounds__(kWG) void k_next(State* st, const unsigned long lon
 // ------------------------------------------------------------------------------------------------
 // Stand-alone operator kernels (operator-level C ABI; same device functions as above)
 // ------------------------------------------------------------------------------------------------
+// value rows [pos0, pos0 + n) of every layer, row-major [layer][seq_len][kv_dim] -> transposed [layer][kv_dim][seq_len]
+// (behind a batched prefill, whose matmul epilogues write the row-major cache only; grid (ceil(kv_dim / 64), ceil(n / 64), layers))
+__global__ __launch_bounds__(kWG) void k_value_transpose(const float* __restrict__ v, float* __restrict__ vt, int seq_len, int kvd, int pos0, int n) {
+    __shared__ float tile[64][65];
+    const size_t lbase = (size_t)blockIdx.z * seq_len * kvd;
+    const int e0 = blockIdx.x * 64, t0 = pos0 + blockIdx.y * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += kWG) {
+        const int r = i >> 6, c = i & 63;                    // row = timestep, column = element
+        tile[r][c] = (t0 + r < pos0 + n && e0 + c < kvd) ? v[lbase + (size_t)(t0 + r) * kvd + e0 + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += kWG) {
+        const int r = i >> 6, c = i & 63;                    // row = element, column = timestep
+        if (t0 + c < pos0 + n && e0 + r < kvd) vt[lbase + (size_t)(e0 + r) * seq_len + t0 + c] = tile[c][r];
+    }
+}
+
 __global__ __launch_bounds__(kWG) void k_op_quantize(int8_t* q, float* s, const float* x, int n, int group) {
     // one workgroup; grid-strides over float4 slots
     const int nv = n >> 2, glanes = group >> 2;
