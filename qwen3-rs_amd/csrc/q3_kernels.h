@@ -1062,6 +1062,28 @@ template <int NW> __device__ __forceinline__ float block_sum_fast_n(float v, flo
 // P_LDS: the probability row lives in LDS (contexts up to kPLds positions) -- a compile-time fact, because a pointer that
 // is LDS or global at run time makes every access a FLAT instruction (slower, and it ties the LDS and vector-memory wait
 // counters together).
+// The V chain's inner step, written out (round 5): request the 8 float4 at LDS byte address `addr` into n[], wait until everything but
+// those 8 reads has landed (the set c[], requested a phase ago), add c's 32 floats to acc in order.  hipcc's own version of this loop
+// reused the last register of a set in flight as the chain's temporary (kernel at its 128-VGPR limit) and paid for it with an
+// `s_waitcnt lgkmcnt(0)` -- a whole LDS round trip -- every 64 timesteps: 9-10 cycles per timestep instead of ~6.
+__device__ __forceinline__ void chain_request8(v4f (&n)[8], unsigned addr) {
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\tds_read_b128 %3, %8 offset:48\n\t"
+                 "ds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\tds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112\n\t"
+                 "s_waitcnt lgkmcnt(8)"
+                 : "=&v"(n[0]), "=&v"(n[1]), "=&v"(n[2]), "=&v"(n[3]), "=&v"(n[4]), "=&v"(n[5]), "=&v"(n[6]), "=&v"(n[7])
+                 : "v"(addr)
+                 : "memory");
+}
+__device__ __forceinline__ void chain_add16(float& acc, v4f c0, v4f c1, v4f c2, v4f c3) {
+    asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %3\n\tv_add_f32 %0, %0, %4\n\t"
+                 "v_add_f32 %0, %0, %5\n\tv_add_f32 %0, %0, %6\n\tv_add_f32 %0, %0, %7\n\tv_add_f32 %0, %0, %8\n\t"
+                 "v_add_f32 %0, %0, %9\n\tv_add_f32 %0, %0, %10\n\tv_add_f32 %0, %0, %11\n\tv_add_f32 %0, %0, %12\n\t"
+                 "v_add_f32 %0, %0, %13\n\tv_add_f32 %0, %0, %14\n\tv_add_f32 %0, %0, %15\n\tv_add_f32 %0, %0, %16"
+                 : "+v"(acc)
+                 : "v"(c0.x), "v"(c0.y), "v"(c0.z), "v"(c0.w), "v"(c1.x), "v"(c1.y), "v"(c1.z), "v"(c1.w),
+                   "v"(c2.x), "v"(c2.y), "v"(c2.z), "v"(c2.w), "v"(c3.x), "v"(c3.y), "v"(c3.z), "v"(c3.w));
+}
+
 template <int W_T, bool P_LDS>
 // (developer timeline, Q3_DEV builds: 1 loads issued, 2 scores in registers, 3 max, 4 exps written, 5 exact sum, 6 end)
 __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
@@ -1113,32 +1135,28 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
     // reference order with a transposed value cache: a staging thread owns 4 consecutive timesteps of one element (float4 q of element e:
     // K / 4 float4 per element and chunk), the chunk of an element is one contiguous run of K floats
     const bool vtr = a.value_t != nullptr && a.strict != 0;              // wave-uniform
-    const float* vtbase = vtr ? a.value_t + ((size_t)kvh * hd + (size_t)sl * w) * (size_t)a.seq_len : nullptr;
+    const float* vtbase = (vtr ? a.value_t : a.value_cache) + ((size_t)kvh * hd + (size_t)sl * w) * (size_t)a.seq_len;   // (a valid address either way)
     constexpr int KQ = kVChunk / 4;
     const int npass_t = (w * KQ + nst - 1) / nst;                        // 1 / 2 / 2 for slice widths 8 / 16 / 32
     auto v_issue = [&](VRegs& R, int c0, bool every_wave = false) {
         if (!every_wave && !stager) return;
-        if (vtr) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (u < npass_t) {
-                    const int idx = min(sid + u * nst, w * KQ - 1);
-                    const int e = idx / KQ, tq = idx % KQ;
-                    const int t = min(c0 + 4 * tq, a.seq_len - 4);      // clamped to the cache (seq_len % 4 == 0: host)
-                    R.v[u] = *(const v4f*)(vtbase + (size_t)e * a.seq_len + t);
-                }
-            }
-            return;
-        }
+        // ONE load per slot whatever the layout -- the address is selected, not the code path: loads behind a (wave-uniform) branch
+        // made hipcc close the block in front of them with vmcnt(0), i.e. wait for the score row before the first value request
+        // ("loads issued" 1,850 -> 3,550 cycles after entry when the transposed form first sat behind its own `if`)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            if (u < npass) {                             // (compile-time for the instantiated slice widths)
-                // clamped to the cache, not to the context: rows past the current position are allocated memory whose
+            if (u < (vtr ? npass_t : npass)) {           // (compile-time for the instantiated slice widths: both counts agree)
+                // row-major: clamped to the cache, not to the context: rows past the current position are allocated memory whose
                 // contents are masked at commit time, and the address then does not wait for the position
                 const int t = min(c0 + r0 + u * rps, a.seq_len - 1);
+                const float* prm = vbase + (size_t)t * kvd + 4 * c4;
+                const int idx = min(sid + u * nst, w * KQ - 1);
+                const int e = idx / KQ, tq = idx % KQ;
+                const int tt = min(c0 + 4 * tq, a.seq_len - 4);      // (seq_len % 4 == 0: host)
+                const float* ptr = vtbase + (size_t)e * a.seq_len + tt;
                 // (developer ablation 1024, timing only: the slice's rows read as if they were stored back to back)
-                R.v[u] = Q3_DEV_ABLATE(a, 1024) ? *(const v4f*)(a.value_cache + ((size_t)((blockIdx.x & 7) * gridDim.y + blockIdx.y) * a.seq_len + t) * w + 4 * c4)
-                                                : *(const v4f*)(vbase + (size_t)t * kvd + 4 * c4);
+                const float* pab = a.value_cache + ((size_t)((blockIdx.x & 7) * gridDim.y + blockIdx.y) * a.seq_len + t) * w + 4 * c4;
+                R.v[u] = *(const v4f*)(Q3_DEV_ABLATE(a, 1024) ? pab : (vtr ? ptr : prm));
             }
         }
     };
@@ -1147,7 +1165,10 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
     // exp2 table of q3_expf staged in LDS (a dependent global load per exp otherwise)
     // (one copy per wave: with the block maxima below no barrier separates the staging of the table from its use)
     unsigned long long* etab = (unsigned long long*)(p_lds + (p_in_lds ? npad_max : 0)) + 32 * wave;
-    if (lane < 32) etab[lane] = kExp2Tab[lane];
+    // (requested here, written to LDS only behind the score / value requests below: the LDS store needs the loaded value, and placed
+    // here it put the table's whole round trip -- a cold constant-memory line -- in front of every other load of the launch)
+    unsigned long long etv = 0ull;
+    if (lane < 32) etv = kExp2Tab[lane];
 
     // ---- softmax (layers.rs:495-506) into this workgroup's private probability row.  The scores are on the critical path
     // and go out first (16 independent loads per thread: one trip covers 4096 positions and the values then stay in
@@ -1174,6 +1195,7 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
     v_issue(vra, 0, true);
     v_issue(vrb, K, true);                               // (row indices are clamped to the cache)
     __builtin_amdgcn_sched_barrier(0);
+    if (lane < 32) etab[lane] = etv;                     // (the oldest load of the wave)
     ATT_STAMP(1);
     const int pos = __builtin_amdgcn_readfirstlane(a.pos_override >= 0 ? a.pos_override : pos_mem);     // wave-uniform -> SGPR
     const int np = pos + 1;
@@ -1421,20 +1443,11 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
                 // the chain is bound by the wave's issue rate (one instruction per ~4.9 cycles): a burst of 8 reads, ONE wait for the
                 // set requested a phase ago, 32 adds -- 1.28 instructions per timestep (a read + a wait behind every fourth add: 1.5)
                 // (the explicit lgkmcnt(8) = "everything but the burst just issued has landed": without it hipcc waits once per float4)
-#pragma unroll
-                for (int u = 0; u < 8; ++u) bv[u] = vr[q + 8 + u];
-                __builtin_amdgcn_s_waitcnt(0xC87F);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) fold4(av[u]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) av[u] = vr[q + 16 + u];
-                __builtin_amdgcn_s_waitcnt(0xC87F);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) fold4(bv[u]);
-                __builtin_amdgcn_sched_barrier(0);
+                const unsigned la = (unsigned)(size_t)(vr + q + 8);          // LDS byte address of the next 8 float4
+                if (!Q3_DEV_ABLATE(a, 2048)) chain_request8(bv, la);
+                if (!Q3_DEV_ABLATE(a, 4096)) { chain_add16(o_s, av[0], av[1], av[2], av[3]); chain_add16(o_s, av[4], av[5], av[6], av[7]); }
+                if (!Q3_DEV_ABLATE(a, 2048)) chain_request8(av, la + 128u);
+                if (!Q3_DEV_ABLATE(a, 4096)) { chain_add16(o_s, bv[0], bv[1], bv[2], bv[3]); chain_add16(o_s, bv[4], bv[5], bv[6], bv[7]); }
             }
             {
                 // the chunk's last 64 timesteps meet the staging waves' barrier.  (Round 5 tried LDS counters instead -- arrival count of
@@ -1442,8 +1455,9 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
                 // of attention per token at position 2,300, but 4 runs in 10 of the 33-chunk operator test returned a wrong 8-element
                 // slice, with or without a compiler barrier around the store.  The barrier stays; what the chain really waits for is
                 // the staging waves' value rows)
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { bv[u] = vr[q + 8 + u]; fold4(av[u]); }
+                chain_request8(bv, (unsigned)(size_t)(vr + q + 8));           // (its wait also covers av, requested by the loop above)
+                chain_add16(o_s, av[0], av[1], av[2], av[3]);
+                chain_add16(o_s, av[4], av[5], av[6], av[7]);
                 if (!Q3_DEV_ABLATE(a, 256)) __syncthreads();     // the staging waves' barrier of this chunk: tile c+1 is complete
                 if (c0 + K < np) {
 #pragma unroll
