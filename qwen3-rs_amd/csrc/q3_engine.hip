@@ -1213,6 +1213,11 @@ int q3_generate_greedy(q3_engine* e, size_t first_token, size_t first_pos, size_
             if (hs[0]) fprintf(stderr, "[q3 stamps] sample (last draw): sum %llu  normalise %llu  histogram %llu  compaction %llu  sort %llu  cumulative walk %llu  cdf walk %llu  total %llu ticks, %llu candidates\n",
                                hs[1] - hs[0], hs[2] - hs[1], hs[3] - hs[2], hs[4] - hs[3], hs[5] - hs[4], hs[6] - hs[5], hs[7] - hs[6], hs[7] - hs[0], hs[9]);
         }
+        if (cnt[F_ATTN] && acc[F_ATTN][7] > 0) {           // k_attn_out: the chain wave in front of each chunk's barrier
+            fprintf(stderr, "[q3 stamps] attn chain wave at the chunk barriers:");
+            for (int k = 7; k < 16; ++k) fprintf(stderr, " %.0f", acc[F_ATTN][k] / cnt[F_ATTN]);
+            fprintf(stderr, "\n");
+        }
         if (cnt[F_ATTN]) fprintf(stderr, "[q3 stamps] attn: issued %.0f  norm %.0f  staged %.0f  scores %.0f  softmax %.0f  vsum %.0f\n", acc[F_ATTN][1] / cnt[F_ATTN], acc[F_ATTN][2] / cnt[F_ATTN], acc[F_ATTN][3] / cnt[F_ATTN], acc[F_ATTN][4] / cnt[F_ATTN], acc[F_ATTN][5] / cnt[F_ATTN], acc[F_ATTN][6] / cnt[F_ATTN]);
     }
 #ifdef Q3_DEV

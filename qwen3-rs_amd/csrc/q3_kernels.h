@@ -1156,7 +1156,8 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
                 const float* ptr = vtbase + (size_t)e * a.seq_len + tt;
                 // (developer ablation 1024, timing only: the slice's rows read as if they were stored back to back)
                 const float* pab = a.value_cache + ((size_t)((blockIdx.x & 7) * gridDim.y + blockIdx.y) * a.seq_len + t) * w + 4 * c4;
-                R.v[u] = *(const v4f*)(Q3_DEV_ABLATE(a, 1024) ? pab : (vtr ? ptr : prm));
+                // (developer ablation 8192, timing only: every request of the launch reads the same 16 bytes)
+                R.v[u] = *(const v4f*)(Q3_DEV_ABLATE(a, 8192) ? a.value_cache : (Q3_DEV_ABLATE(a, 1024) ? pab : (vtr ? ptr : prm)));
             }
         }
     };
@@ -1234,34 +1235,40 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
     float part = 0.0f;
     const int nblk_terms = ((np + bl - 1) >> blsh) << blsh;
     if (one_trip) {
-        // exps in groups of four (their f64 chains interleave; a guard around each one would serialise them), whole groups
-        // past the padded row skipped
+        // Only the exps this WAVE has live slots for (wave-uniform count): the phase is bound by the SIMD's instruction rate -- four waves
+        // per SIMD, ~75 instructions per exp -- and at 2,300 positions the unconditional four per thread computed 4,096 exps for 2,304
+        // slots (timeline of the 4B shape at position 2,300: 4,750 cycles from the maximum to the last exp written).  Inside a count the
+        // exps stay one basic block (their f64 chains interleave; a guard around each one would serialise them).
+        static_assert(kAoSv == 4, "one group of four slots per thread");
+        const int nu = min(4, max(0, (npad - wave * 64 + kAoThreads - 1) / kAoThreads));
+        auto exps = [&](auto NU) {
+            constexpr int N = decltype(NU)::value;
+            float ev[N];
 #pragma unroll
-        for (int g = 0; g < kAoSv / 4; ++g) {
-            if (g * 4 * kAoThreads < npad) {
-                float ev[4];
+            for (int u = 0; u < N; ++u) {
+                const int t = u * kAoThreads + tid;
+                const float e = q3_expf_t(t < np ? sv[u] - m : 0.0f, etab);
+                ev[u] = t < np ? e : 0.0f;               // +0.0 padding leaves every partial sum unchanged
+            }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int t = (g * 4 + u) * kAoThreads + tid;
-                    const float e = q3_expf_t(t < np ? sv[g * 4 + u] - m : 0.0f, etab);
-                    ev[u] = t < np ? e : 0.0f;           // +0.0 padding leaves every partial sum unchanged
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int t = (g * 4 + u) * kAoThreads + tid;
-                    part = part + ev[u];
-                    if constexpr (P_LDS) {
-                        // masked-off stores go to a dummy word instead of sitting behind a branch: LLVM sinks the whole exp
-                        // into a guarded block otherwise and the four chains no longer interleave
-                        *(t < npad ? p + t : dummy) = ev[u];
-                        *((padded && t < nblk_terms) ? esc + (t >> blsh) * (bl + kSpecPad) + (t & (bl - 1)) : dummy) = ev[u];
-                    } else if (t < npad) {
-                        p[t] = ev[u];
-                        if (padded && t < nblk_terms) esc[(t >> blsh) * (bl + kSpecPad) + (t & (bl - 1))] = ev[u];
-                    }
+            for (int u = 0; u < N; ++u) {
+                const int t = u * kAoThreads + tid;
+                part = part + ev[u];
+                if constexpr (P_LDS) {
+                    // masked-off stores go to a dummy word instead of sitting behind a branch: LLVM sinks the whole exp
+                    // into a guarded block otherwise and the chains no longer interleave
+                    *(t < npad ? p + t : dummy) = ev[u];
+                    *((padded && t < nblk_terms) ? esc + (t >> blsh) * (bl + kSpecPad) + (t & (bl - 1)) : dummy) = ev[u];
+                } else if (t < npad) {
+                    p[t] = ev[u];
+                    if (padded && t < nblk_terms) esc[(t >> blsh) * (bl + kSpecPad) + (t & (bl - 1))] = ev[u];
                 }
             }
-        }
+        };
+        if (nu == 4) exps(IntC<4>{});
+        else if (nu == 3) exps(IntC<3>{});
+        else if (nu == 2) exps(IntC<2>{});
+        else if (nu == 1) exps(IntC<1>{});
     } else {
         for (int t0 = 0; t0 < npad; t0 += 4 * kAoThreads) {
             float s2[4], ev[4];
@@ -1418,21 +1425,15 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
         const int row = min(tid, w - 1);
         // (round 5: s_setprio 3 for this wave -- it shares its SIMD with three staging waves -- measured, no change: 905.8 vs 905.4 us
         // of attention per token at position 2,300 on the 4B dims; the staging waves do not take the chain's issue slots)
-        auto fold4 = [&](v4f x) {
-            o_s = o_s + x.x;
-            o_s = o_s + x.y;
-            o_s = o_s + x.z;
-            o_s = o_s + x.w;
-        };
         // Operands run 32 timesteps ahead of the adds (two sets of 8 float4): a dependent v_add_f32 issues every ~4.9 cycles
         // (tools/mfma_chain_probe.hip; the "10 cycles" of rounds 2-3 included the timer's own latency over a 64-step loop), so the
         // 16 adds that used to cover an LDS read were 78 cycles against a ~130-cycle round trip, and the chain ran at 11.3 per step.
+        // EVERY LDS read of the two sets goes through chain_request8: one read of av left to hipcc (the hand-over to the next tile was
+        // `av[u] = vn[u]`) put those registers on its scoreboard at the loop header, and it then guarded the written-out adds with
+        // lgkmcnt(4) / lgkmcnt(0) -- counters that include the burst just issued, i.e. the LDS round trip every 64 timesteps again
+        // (timeline: 2,460 cycles per 256-timestep chunk = 9.6 per timestep against ~6 for the chain by itself).
         v4f av[8], bv[8];
-        {
-            const v4f* v0 = (const v4f*)(vbuf0 + row * VLD);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) av[u] = v0[u];
-        }
+        chain_request8(av, (unsigned)(size_t)(vbuf0 + row * VLD));
         for (int c0 = 0, buf = 0; c0 < np; c0 += K, buf ^= 1) {
             const int cnt = min(K, np - c0);
             const int nq16 = ((cnt + 63) >> 6) << 4;         // float4 steps, whole blocks of 16 (zero padded, <= K/4)
@@ -1458,15 +1459,18 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
                 chain_request8(bv, (unsigned)(size_t)(vr + q + 8));           // (its wait also covers av, requested by the loop above)
                 chain_add16(o_s, av[0], av[1], av[2], av[3]);
                 chain_add16(o_s, av[4], av[5], av[6], av[7]);
+                // (developer timeline: the chain wave in front of / behind the barriers of chunks 2..5)
+                if (c0 >= 2 * K && c0 < 6 * K) ATT_STAMP(7 + 2 * (c0 / K - 2));
                 if (!Q3_DEV_ABLATE(a, 256)) __syncthreads();     // the staging waves' barrier of this chunk: tile c+1 is complete
-                if (c0 + K < np) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) av[u] = vn[u];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) fold4(bv[u]);
+                if (c0 >= 2 * K && c0 < 6 * K) ATT_STAMP(8 + 2 * (c0 / K - 2));
+                chain_request8(av, (unsigned)(size_t)vn);        // head of the next tile (past the last chunk: a valid address, unused);
+                                                                 // its wait = bv has landed
+                chain_add16(o_s, bv[0], bv[1], bv[2], bv[3]);
+                chain_add16(o_s, bv[4], bv[5], bv[6], bv[7]);
             }
         }
+        // the last request is still in flight and hipcc does not know: its registers must not be handed out before it has landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     } else
     for (int c0 = 0; c0 < np; c0 += 2 * K) {
         if (c0 + K < np) {
