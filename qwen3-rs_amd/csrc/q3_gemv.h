@@ -143,6 +143,30 @@ static __device__ __constant__ unsigned long long kExp2Tab[32] = {
 
 // `tab`: the 32-entry exp2 table -- kExp2Tab in constant memory (a dependent global load in the middle of the
 // evaluation), or a copy the kernel staged in LDS (latency-critical single-wave phases).
+// glibc's main path alone: THE result for |x| < 88 (q3_expf_special says which inputs those are); a caller that has checked a whole
+// batch skips the special-case selects of q3_expf_t (k_attn_out's exp phase is bound by its instruction count)
+__device__ __forceinline__ bool q3_expf_special(float x) { return ((__float_as_uint(x) >> 20) & 0x7ffu) >= 0x42bu; }   // |x| >= 88 or not finite
+__device__ __forceinline__ float q3_expf_main(float x, const unsigned long long* tab) {
+    constexpr double kInvLn2N = 0x1.71547652b82fep+0 * 32.0;
+    constexpr double kShift = 0x1.8p+52;
+    constexpr double kC0 = 0x1.c6af84b912394p-5 / 32.0 / 32.0 / 32.0;
+    constexpr double kC1 = 0x1.ebfce50fac4f3p-3 / 32.0 / 32.0;
+    constexpr double kC2 = 0x1.62e42ff0c52d6p-1 / 32.0;
+    const double xd = (double)x;
+    double z = kInvLn2N * xd;
+    double kd = z + kShift;
+    const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+    kd -= kShift;
+    const double r = z - kd;
+    const unsigned long long t = tab[ki & 31u] + (ki << 47);
+    const double s = __longlong_as_double((long long)t);
+    z = kC0 * r + kC1;
+    const double r2 = r * r;
+    double y = kC2 * r + 1.0;
+    y = z * r2 + y;
+    y = y * s;
+    return (float)y;
+}
 __device__ __forceinline__ float q3_expf_t(float x, const unsigned long long* tab) {
     // Branch-free: the main path is evaluated for every input and the special cases (|x| >= 88: overflow, underflow,
     // infinities, NaN) are patched in with selects afterwards, so several independent exps interleave in one wave

@@ -1084,6 +1084,17 @@ __device__ __forceinline__ void chain_add16(float& acc, v4f c0, v4f c1, v4f c2, 
                    "v"(c2.x), "v"(c2.y), "v"(c2.z), "v"(c2.w), "v"(c3.x), "v"(c3.y), "v"(c3.z), "v"(c3.w));
 }
 
+// exact sum over blocks of 4 * nq terms, nq = 1 ... 16: every length as straight-line register code
+__device__ __forceinline__ float seq_sum_blocks_nq16(const float* t, int nblk, int nq, int stride) {
+    switch (nq) {
+#define Q3_NQ_CASE(N) case N: return seq_sum_blocks_regs<N>(t, nblk, stride, nullptr);
+        Q3_NQ_CASE(1) Q3_NQ_CASE(2) Q3_NQ_CASE(3) Q3_NQ_CASE(4) Q3_NQ_CASE(5) Q3_NQ_CASE(6) Q3_NQ_CASE(7) Q3_NQ_CASE(8)
+        Q3_NQ_CASE(9) Q3_NQ_CASE(10) Q3_NQ_CASE(11) Q3_NQ_CASE(12) Q3_NQ_CASE(13) Q3_NQ_CASE(14) Q3_NQ_CASE(15) Q3_NQ_CASE(16)
+#undef Q3_NQ_CASE
+    }
+    return seq_sum_blocks(t, nblk, 4 * nq, stride, nullptr);
+}
+
 template <int W_T, bool P_LDS>
 // (developer timeline, Q3_DEV builds: 1 loads issued, 2 scores in registers, 3 max, 4 exps written, 5 exact sum, 6 end)
 __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
@@ -1201,13 +1212,16 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
     const int pos = __builtin_amdgcn_readfirstlane(a.pos_override >= 0 ? a.pos_override : pos_mem);     // wave-uniform -> SGPR
     const int np = pos + 1;
     const int npad = (np + 255) & ~255;                  // whole 64 x (npad/64) blocks for the exact sum
-    int bl = 4;
-    while (64 * bl < np) bl <<= 1;                       // 4 .. 64 for np <= 4096
-    const bool padded = a.strict && bl <= 64;
-    const int blsh = __builtin_ctz(bl);
+    // exact-sum blocks: 64 lanes x the fewest whole float4 that cover the row (np <= 4096: 4 ... 64 terms; the 36 terms of position 2,300
+    // fold in 165 cycles per round where the power-of-two block of 64 took 295), stride padded to an odd number of float4 (b128 reads of
+    // 16 consecutive lanes on 16 different bank groups).  t / bl as a multiplication: exact for t < 4,160 and bl <= 64 (t * bl < 2^20)
+    const bool one_trip = np <= kAoSv * kAoThreads;
+    const int blq = (np + 255) >> 8;
+    const int bl = 4 * blq, estride = 4 * (blq + 1 + (blq & 1));
+    const unsigned bmag = one_trip ? (1048576u + (unsigned)bl - 1u) / (unsigned)bl : 0u;
+    const bool padded = a.strict && one_trip;
     float* esc = vbuf0;                                  // (np/bl) x (bl + 4) floats <= kEscFloats: the V-tile region reserves that much
     float m = -__builtin_inff();
-    const bool one_trip = np <= kAoSv * kAoThreads;
 #pragma unroll
     for (int u = 0; u < kAoSv; ++u) sv[u] = (u * kAoThreads + tid < np) ? sv[u] : -__builtin_inff();
     if (have_cmax) {
@@ -1233,7 +1247,7 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
     }
     ATT_STAMP(3);
     float part = 0.0f;
-    const int nblk_terms = ((np + bl - 1) >> blsh) << blsh;
+    const int nblk = (int)(((unsigned)(np + bl - 1) * bmag) >> 20), nblk_terms = nblk * bl;     // (one_trip rows)
     if (one_trip) {
         // Only the exps this WAVE has live slots for (wave-uniform count): the phase is bound by the SIMD's instruction rate -- four waves
         // per SIMD, ~75 instructions per exp -- and at 2,300 positions the unconditional four per thread computed 4,096 exps for 2,304
@@ -1241,27 +1255,37 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
         // exps stay one basic block (their f64 chains interleave; a guard around each one would serialise them).
         static_assert(kAoSv == 4, "one group of four slots per thread");
         const int nu = min(4, max(0, (npad - wave * 64 + kAoThreads - 1) / kAoThreads));
+        auto esc_at = [&](int t) { const int b = (int)(((unsigned)t * bmag) >> 20); return b * estride + (t - b * bl); };
         auto exps = [&](auto NU) {
             constexpr int N = decltype(NU)::value;
-            float ev[N];
+            float xv[N], ev[N];
+            bool sp = false;
 #pragma unroll
             for (int u = 0; u < N; ++u) {
-                const int t = u * kAoThreads + tid;
-                const float e = q3_expf_t(t < np ? sv[u] - m : 0.0f, etab);
-                ev[u] = t < np ? e : 0.0f;               // +0.0 padding leaves every partial sum unchanged
+                xv[u] = u * kAoThreads + tid < np ? sv[u] - m : 0.0f;
+                sp = sp || q3_expf_special(xv[u]);
+            }
+            // (wave-uniform: the selects of the special cases -- a sixth of an exp's instructions -- only where some lane needs them)
+            if (__builtin_expect(__any(sp), 0)) {
+#pragma unroll
+                for (int u = 0; u < N; ++u) ev[u] = q3_expf_t(xv[u], etab);
+            } else {
+#pragma unroll
+                for (int u = 0; u < N; ++u) ev[u] = q3_expf_main(xv[u], etab);
             }
 #pragma unroll
             for (int u = 0; u < N; ++u) {
                 const int t = u * kAoThreads + tid;
+                ev[u] = t < np ? ev[u] : 0.0f;           // +0.0 padding leaves every partial sum unchanged
                 part = part + ev[u];
                 if constexpr (P_LDS) {
                     // masked-off stores go to a dummy word instead of sitting behind a branch: LLVM sinks the whole exp
                     // into a guarded block otherwise and the chains no longer interleave
                     *(t < npad ? p + t : dummy) = ev[u];
-                    *((padded && t < nblk_terms) ? esc + (t >> blsh) * (bl + kSpecPad) + (t & (bl - 1)) : dummy) = ev[u];
+                    *((padded && t < nblk_terms) ? esc + esc_at(t) : dummy) = ev[u];
                 } else if (t < npad) {
                     p[t] = ev[u];
-                    if (padded && t < nblk_terms) esc[(t >> blsh) * (bl + kSpecPad) + (t & (bl - 1))] = ev[u];
+                    if (padded && t < nblk_terms) esc[esc_at(t)] = ev[u];
                 }
             }
         };
@@ -1285,8 +1309,7 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
                 const int t = t0 + u * kAoThreads + tid;
                 if (t < npad) {
                     part = part + ev[u];
-                    p[t] = ev[u];
-                    if (padded && t < nblk_terms) esc[(t >> blsh) * (bl + kSpecPad) + (t & (bl - 1))] = ev[u];
+                    p[t] = ev[u];                        // (rows beyond 4096 positions: the exact sum reads p itself)
                 }
             }
         }
@@ -1296,7 +1319,7 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
     float sum;
     if (a.strict) {
         if (wave == 0) {                                 // one wave walks the blocks; the other 15 would only fight it for LDS
-            if (padded) sum = seq_sum_blocks(esc, (np + bl - 1) >> blsh, bl, bl + kSpecPad, nullptr);
+            if (padded) sum = seq_sum_blocks_nq16(esc, nblk, blq, estride);
             else sum = seq_sum_blocks(p, 64, npad >> 6, npad >> 6, nullptr);    // rows beyond 4096 positions: 64 longer blocks out of LDS
             if (tid == 0) red[0] = sum;
         }

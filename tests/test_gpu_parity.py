@@ -238,6 +238,25 @@ def test_attention_long_context(ops, oracle, nh, nkv, hd, S, pos):
     assert np.max(np.abs(xb - rb)) <= FAST_TOL
 
 
+def test_attention_split_path_every_exact_sum_block_length(ops, oracle):
+    """k_attn_out's exact softmax sum runs on 64 lanes x blocks of 4 * ceil(np / 256) terms: every block length 8 ... 64 and the rows that
+    end on / next to a block or a 256-position boundary, bit for bit (layers.rs:495-506, 406-417)."""
+    nh, nkv, hd, S = 4, 2, 128, 4096
+    rng = np.random.default_rng(77)
+    kvd = nkv * hd
+    q = rng.standard_normal(nh * hd).astype(np.float32)
+    K = (rng.standard_normal((S, kvd)) * 0.5).astype(np.float32)
+    V = rng.standard_normal((S, kvd)).astype(np.float32)
+    qw = (1.0 + 0.1 * rng.standard_normal(hd)).astype(np.float32)
+    kw = (1.0 + 0.1 * rng.standard_normal(hd)).astype(np.float32)
+    for pos in [256, 300, 511, 512, 700, 767, 1023, 1024, 1100, 1290, 1535, 1800, 2047, 2048, 2300, 2303, 2304, 2600, 2815, 2816, 3000, 3300,
+                3500, 3583, 3839, 3840, 4000, 4095]:
+        rb, _, rk = oracle.attention(q, K, V, qw, kw, pos, nh, nkv, hd)
+        xb, _, k2 = ops.attention(q, K, V, qw, kw, pos, nh, nkv, hd, strict=True)
+        assert_biteq(xb, rb, f"xb at position {pos}")
+        assert_biteq(k2.reshape(S, kvd)[pos], rk.reshape(S, kvd)[pos], f"K row at position {pos}")
+
+
 def test_eager_launch_mode_matches_graph(q3):
     """Q3_FLAG_NO_GRAPH launches the same kernel chain eagerly: identical logits and tokens."""
     path = golden_path("tiny-untied.bin")
