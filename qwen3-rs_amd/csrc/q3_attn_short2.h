@@ -69,9 +69,9 @@ __global__ __launch_bounds__(kS2Threads) void k_attn_short2(const AttnArgs a) {
     // workgroup -> head: the hardware deals workgroups round-robin over the 8 XCDs (linear id % 8), each with its own L2.  The query
     // heads of one kv head read the same key / value rows, so they take block indices that are equal modulo n_kv_heads (8 for every
     // listed model): the rows cross the fabric into ONE L2 and the other workgroups of the group hit there.
-    const int kv_mul = a.n_heads / a.n_kv_heads;
-    const int kvh = (int)blockIdx.x % a.n_kv_heads;
-    const int h = kvh * kv_mul + (int)blockIdx.x / a.n_kv_heads;
+    const int kv_mul = a.kv_mul, xq = (int)((blockIdx.x * a.kvh_magic) >> 20);     // (attn_set_heads: no integer division here)
+    const int kvh = (int)blockIdx.x - xq * a.n_kv_heads;
+    const int h = kvh * kv_mul + xq;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t kvd = (size_t)a.n_kv_heads * HD;
@@ -242,7 +242,13 @@ __global__ __launch_bounds__(kS2Threads) void k_attn_short2(const AttnArgs a) {
         // ================================ staging waves: key rows 0 .. pos-1 (value rows 0 .. pos), coalesced, into LDS
         unsigned long long etv = 0ull;
         if (wave == 7 && lane < 32) etv = kExp2Tab[lane];
-        const int hint = a.row_steps;                     // > 0: 8-row steps to request without waiting for the position (pos < 64)
+        // > 0: 8-row steps to request without waiting for the position (pos < 64) -- the position-range graphs lost their A/B
+        //  and exist in the developer build only; the product does not fetch the field
+#ifdef Q3_DEV
+        const int hint = a.row_steps;
+#else
+        constexpr int hint = 0;
+#endif
         if (hint <= 0) {
             pos = __builtin_amdgcn_readfirstlane(pos_v);
             np = pos + 1;

@@ -746,8 +746,7 @@ int q3_engine::build_plan() {
             a.att_global = use_att_global ? d_att : nullptr;
             a.st = d_state;
             a.pos_override = -1;
-            a.n_heads = cfg.n_heads;
-            a.n_kv_heads = cfg.n_kv_heads;
+            attn_set_heads(a, cfg.n_heads, cfg.n_kv_heads);
             a.hd = hd;
             a.seq_len = S;
             a.strict = strict;
@@ -1721,8 +1720,7 @@ int q3_op_attention(float* xb, float* q, float* key_cache_layer, const float* va
     a.att_global = att_global ? datt.as<float>() : nullptr;
     a.st = nullptr;
     a.pos_override = (int)pos;
-    a.n_heads = (int)n_heads;
-    a.n_kv_heads = (int)n_kv_heads;
+    attn_set_heads(a, (int)n_heads, (int)n_kv_heads);
     a.hd = (int)head_dim;
     a.seq_len = (int)seq_len;
     a.strict = (flags & Q3_FLAG_FAST) ? 0 : 1;

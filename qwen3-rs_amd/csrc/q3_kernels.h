@@ -99,7 +99,17 @@ struct AttnArgs {
     int att_short_form;       // host bookkeeping: 1 = keep k_attn_short where k_attn_short2 is eligible (A/B)
     int row_steps;            // k_attn_short2: > 0 = 8-row steps of K / V to request at kernel entry (the graph of a position range < 64)
     const float* value_t;     // k_attn_out: transposed value cache of this layer, [kv_dim][seq_len] (nullptr: stage from value_cache)
+    // k_attn_short2 / k_attn_out: n_heads / n_kv_heads and ceil(2^20 / n_kv_heads), set by attn_set_heads -- the workgroup -> head mapping
+    // without two integer divisions (~55 scalar instructions in front of the first address that needs the head)
+    int kv_mul;
+    unsigned kvh_magic;
 };
+inline void attn_set_heads(AttnArgs& a, int n_heads, int n_kv_heads) {
+    a.n_heads = n_heads;
+    a.n_kv_heads = n_kv_heads;
+    a.kv_mul = n_heads / n_kv_heads;
+    a.kvh_magic = (1048576u + (unsigned)n_kv_heads - 1u) / (unsigned)n_kv_heads;     // exact quotient for block index * n_kv_heads < 2^20
+}
 
 // LDS plan of k_attn (floats): q_s[hd] k_s[hd] raw[2hd] sq[2hd] opart[kWaves*hd] red[64] att[att_lds]
 //                              kbuf[TCH][hd+4] vbuf[TCH][hd]
@@ -1112,8 +1122,8 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
     // k_attn_short2): the kv head's value rows enter ONE L2 instead of up to eight
     const int sl = blockIdx.y, nsl = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kv_mul = a.n_heads / a.n_kv_heads, kvh = (int)blockIdx.x % a.n_kv_heads;
-    const int h = kvh * kv_mul + (int)blockIdx.x / a.n_kv_heads;
+    const int kv_mul = a.kv_mul, xq = (int)((blockIdx.x * a.kvh_magic) >> 20), kvh = (int)blockIdx.x - xq * a.n_kv_heads;
+    const int h = kvh * kv_mul + xq;
     const size_t kvd = (size_t)a.n_kv_heads * hd;
     const float* src = a.att_global + (size_t)h * a.att_stride;
     const int npad_max = (a.seq_len + 255) & ~255;

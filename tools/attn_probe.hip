@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
     auto args = [&](int which) {
         AttnArgs a; memset(&a, 0, sizeof(a));
         a.q = dq; a.key_cache = dkc[which]; a.k_raw = dk; a.value_cache = dvc; a.q_norm_w = dqw; a.k_norm_w = dkw; a.rope = drope; a.xb = dxb[which];
-        a.st = dst; a.pos_override = -1; a.n_heads = n_heads; a.n_kv_heads = n_kv; a.hd = HD; a.seq_len = S; a.strict = 1;
+        a.st = dst; a.pos_override = -1; attn_set_heads(a, n_heads, n_kv); a.hd = HD; a.seq_len = S; a.strict = 1;
         a.xbq = dxbq[which]; a.xbs = dxbs[which]; a.xb_group = 64; a.stamps = dstamps;
         return a;
     };
