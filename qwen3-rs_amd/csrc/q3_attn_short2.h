@@ -382,7 +382,7 @@ __global__ __launch_bounds__(kS2Threads) void k_attn_short2(const AttnArgs a) {
     m = group_max_f32(m, 64);
     float ev = 0.0f;                                      // +0.0 past the context: leaves every partial sum unchanged
     if (64 * wave < np) {                                 // wave-uniform
-        ev = q3_expf_t(t < np ? sc - m : 0.0f, etab);
+        ev = q3_expf_wave(t < np ? sc - m : 0.0f, etab);
         ev = t < np ? ev : 0.0f;
     }
     att_e[t] = ev;

@@ -203,6 +203,11 @@ __device__ __forceinline__ float q3_expf_t(float x, const unsigned long long* ta
     return special ? sp : res;
 }
 __device__ __forceinline__ float q3_expf(float x) { return q3_expf_t(x, kExp2Tab); }
+// one exp per lane on a latency path: the special-case selects (a sixth of the instructions) only when some active lane needs them
+__device__ __forceinline__ float q3_expf_wave(float x, const unsigned long long* tab) {
+    if (__builtin_expect(__any(q3_expf_special(x)), 0)) return q3_expf_t(x, tab);
+    return q3_expf_main(x, tab);
+}
 
 // f32::total_cmp key (sampler.rs:57-59): unsigned order of the key == IEEE total order
 __device__ __forceinline__ unsigned total_order_key(float f) {
@@ -1344,7 +1349,7 @@ __global__ __launch_bounds__(WGT) void k_gemv(const GemvArgs a) {
             } else if (EPI == EPI_SWIGLU) {
                 float u = up;
                 if constexpr (FIN == 0) u = ordered_row_sum(term + (lane + HU) * ng, ng);
-                const float den = 1.0f + q3_expf_t(-acc, sm.etab);   // layers.rs:472-475
+                const float den = 1.0f + q3_expf_wave(-acc, sm.etab);   // layers.rs:472-475
                 const float sw = acc * (1.0f / den);
                 rs.out[lane] = sw * u;
             } else if (EPI == EPI_LOGITS) {
