@@ -2219,9 +2219,18 @@ __global__ __launch_bounds__(64 * NP * (KVM / 2), NP * (KVM / 2) / 4) void k_att
                 for (int t0 = 0; t0 < np; t0 += 256) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) xn[u] = row[min(t0 + 256 + 64 * u + lane, np - 1)];
-                    float ev[4];
+                    float ev[4], xx[4];
+                    bool sp = false;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) ev[u] = q3_expf_t(xc[u] - m, etab);
+                    for (int u = 0; u < 4; ++u) { xx[u] = xc[u] - m; sp = sp || q3_expf_special(xx[u]); }
+                    // (wave-uniform: glibc's main path alone unless some lane is outside |x| < 88 -- a sixth of an exp's instructions)
+                    if (__builtin_expect(__any(sp), 0)) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) ev[u] = q3_expf_t(xx[u], etab);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) ev[u] = q3_expf_main(xx[u], etab);
+                    }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int t = t0 + 64 * u + lane;
