@@ -1209,8 +1209,8 @@ int q3_generate_greedy(q3_engine* e, size_t first_token, size_t first_pos, size_
         if (e->sampling) {
             unsigned long long hs[16];
             HIP_TRY(hipMemcpy(hs, e->d_stamps + 16 * (size_t)(5 * e->cfg.n_layers + 3), sizeof(hs), hipMemcpyDeviceToHost));
-            if (hs[0]) fprintf(stderr, "[q3 stamps] sample (last draw): sum %llu  normalise %llu  histogram %llu  compaction %llu  sort %llu  cumulative walk %llu  cdf walk %llu  total %llu ticks, %llu candidates\n",
-                               hs[1] - hs[0], hs[2] - hs[1], hs[3] - hs[2], hs[4] - hs[3], hs[5] - hs[4], hs[6] - hs[5], hs[7] - hs[6], hs[7] - hs[0], hs[9]);
+            if (hs[0]) fprintf(stderr, "[q3 stamps] sample (last draw): sum %llu  normalise %llu  histogram %llu  compaction %llu  sort %llu  cumulative walk %llu  cdf walk %llu  total %llu ticks, %llu candidates, %llu rounds of the exact denominator\n",
+                               hs[1] - hs[0], hs[2] - hs[1], hs[3] - hs[2], hs[4] - hs[3], hs[5] - hs[4], hs[6] - hs[5], hs[7] - hs[6], hs[7] - hs[0], hs[9], hs[10]);
         }
         if (cnt[F_ATTN] && acc[F_ATTN][7] > 0) {           // k_attn_out: the chain wave in front of each chunk's barrier
             fprintf(stderr, "[q3 stamps] attn chain wave at the chunk barriers:");

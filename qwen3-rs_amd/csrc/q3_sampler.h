@@ -66,64 +66,65 @@ __device__ __forceinline__ float key_to_float(unsigned k) {
     return __uint_as_float(b);
 }
 
-// inclusive scan of one float per thread over the whole workgroup (any association: guesses / corrections only)
+// inclusive scan of one float per thread over the whole workgroup (any association: guesses / corrections only): DPP scan inside the
+// waves, ONE barrier, every wave scans the 16 wave totals itself.  wtot: 16 floats of LDS nobody else touches until the next barrier.
 __device__ __forceinline__ float wg_scan_incl(float v, float* wtot) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    v += dpp_f<0x111>(v);
-    v += dpp_f<0x112>(v);
-    v += dpp_f<0x114>(v);
-    v += dpp_f<0x118>(v);
-    const float r0 = __shfl(v, 15), r1 = __shfl(v, 31), r2 = __shfl(v, 47);
-    const int row = lane >> 4;
-    if (row == 1) v += r0;
-    else if (row == 2) v += r0 + r1;
-    else if (row == 3) v += (r0 + r1) + r2;
-    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    v = wave_scan_incl(v);
     if (lane == 63) wtot[wave] = v;
     __syncthreads();
-    float off = 0.0f;
-    for (int w = 0; w < wave; ++w) off += wtot[w];
+    float t = lane < kSampThreads / 64 ? wtot[lane] : 0.0f;
+    t = wave_scan_incl(t);
+    const float off = wave > 0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), wave - 1)) : 0.0f;
     return v + off;
 }
 
-// Exact running sums of t[0 .. 1024*blen) (non-negative terms, blen % 4 == 0) folded in index order from `init`:
-// lane j returns in_j = sum before its block [j*blen, (j+1)*blen) and out_j = sum after it, both bit-exact.
-// xch: >= 1024 + 16 floats of LDS.  Every thread of the 1024-thread workgroup must call it.
-__device__ __forceinline__ void wg_exact_prefix(const float* t, int blen, float init, float* xch, float& in_j, float& out_j,
-                                                int* rounds_out = nullptr) {
-    const int j = threadIdx.x;
-    const v4f* blk = (const v4f*)(t + (size_t)j * blen);
-    const int nq = blen >> 2;
-    float* wtot = xch + kSampThreads;
+// Exact running sums of 1024 x 16 non-negative terms folded in index order from `init`, lane j holding terms [16 j, 16 j + 16) in r[]: it
+// returns in_j = sum before its block and out_j = sum after it, both bit-exact.  xch: >= 80 floats of LDS.  Every thread of the 1024-thread workgroup must call it.
+// Round 5 re-cut (the exact denominator over the 151,936-entry vocabulary took ~65 us = 10 segments x ~7 rounds x ~2,300 cycles): a round is
+// the 16-add fold out of REGISTERS, the neighbour's output by DPP (LDS only across the 16 wave boundaries), the verify folded into the
+// correction scan (a mismatch flag travels with it), and two barriers instead of seven; buffers alternate by round parity.
+__device__ __forceinline__ void wg_exact_prefix(const v4f (&r)[4], float init, float* xch, float& in_j, float& out_j, int* rounds_out = nullptr) {
+    const int j = threadIdx.x, lane = j & 63, wave = __builtin_amdgcn_readfirstlane(j >> 6);
+    constexpr int NW = kSampThreads / 64;
+    float* wtot = xch;                        // [2][NW]
+    float* bnd = xch + 2 * NW;                // [2][NW] last output of every wave
+    int* flag = (int*)(xch + 4 * NW);         // [2] "some link does not match"
+    auto fold = [&](float s) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s = chain4(s, r[q]);
+        return s;
+    };
     // approximate block total (any order)
-    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-    for (int q = 0; q < nq; ++q) {
-        const v4f v = blk[q];
-        p0 += v.x; p1 += v.y; p2 += v.z; p3 += v.w;
-    }
-    const float tot = (p0 + p1) + (p2 + p3);
-    float g = init + (wg_scan_incl(tot, wtot) - tot);      // guessed input of block j
+    const v4f ps = (r[0] + r[1]) + (r[2] + r[3]);
+    const float tot = (ps.x + ps.y) + (ps.z + ps.w);
+    if (j == 0) { flag[0] = 0; flag[1] = 0; }
+    float g = init + (wg_scan_incl(tot, wtot + NW) - tot);      // guessed input of block j (its barrier also publishes the flags)
     if (j == 0) g = init;
-    float out = seq_chain(g, blk, nq);
+    float out = 0.0f;
     for (int round = 0; round < kSampThreads + 1; ++round) {
-        __syncthreads();
-        xch[j] = out;
-        __syncthreads();
-        float e = (j == 0) ? 0.0f : xch[j - 1] - g;         // mismatch at link j
-        e = wg_scan_incl(e, wtot);
-        float sc = g + e;
-        if (j == 0) sc = init;
-        const float out2 = seq_chain(sc, blk, nq);
-        __syncthreads();
-        xch[j] = out2;
-        __syncthreads();
-        const bool ok = (j == 0) || (__float_as_uint(xch[j - 1]) == __float_as_uint(sc));
-        g = sc;
-        out = out2;
-        if (__syncthreads_and(ok)) {                        // block 0 is exact by construction; round r fixes block r
+        const int p = round & 1;
+        out = fold(g);
+        if (lane == 63) bnd[p * NW + wave] = out;
+        __syncthreads();                                        // A: wave-boundary outputs; last round's readers of flag[p ^ 1] are through
+        if (j == 0) flag[p ^ 1] = 0;
+        float prev = wave_prev_lane(out);                       // lane - 1's output (lane 0: +0.0)
+        if (lane == 0 && wave > 0) prev = bnd[p * NW + wave - 1];
+        const bool ok = (j == 0) || (__float_as_uint(prev) == __float_as_uint(g));     // every link bitwise
+        float e = (j == 0) ? 0.0f : prev - g;                   // mismatch at link j
+        if (__any(!ok) && lane == 0) flag[p] = 1;
+        float v = wave_scan_incl(e);
+        if (lane == 63) wtot[p * NW + wave] = v;
+        __syncthreads();                                        // B: flag[p], wave totals of the corrections
+        if (flag[p] == 0) {                                     // (uniform) block 0 is exact by construction; round r fixes block r
             if (rounds_out != nullptr && j == 0) *rounds_out = round + 1;
             break;
         }
+        float tw = lane < NW ? wtot[p * NW + lane] : 0.0f;
+        tw = wave_scan_incl(tw);
+        const float off = wave > 0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tw), wave - 1)) : 0.0f;
+        g = g + (v + off);                                      // corrected inputs under the translation assumption (spec_sum_lanes)
+        if (j == 0) g = init;
     }
     in_j = g;
     out_j = out;
@@ -161,24 +162,25 @@ __device__ __forceinline__ int wg_first_crossing(const float* t, int blen, float
     return red[1];
 }
 
-// The sequences are far longer than what a lane should re-read from L2 on every correction round, so they are walked in
-// segments of kSegFloats terms staged ONCE in LDS (16 terms per lane): the exact running sum at the end of a segment is
-// the `init` of the next.  visit(seg_base, in_j, out_j) runs after each segment's exact prefix (lane j: terms
-// [seg_base + 16 j, +16)) and returns true to stop early.  Returns the exact running sum after the last segment walked.
+// The sequences are walked in segments of kSegFloats terms: lane j holds terms [base + 16 j, + 16) of a segment in REGISTERS (requested
+// straight from global memory, the next segment's before the current segment's rounds start; round 5: the LDS staging pass and its
+// 4-way conflicted read-back cost more than the rounds of a late segment) and the exact running sum at the end of a segment is the
+// `init` of the next.  visit(seg_base, in_j, out_j) runs after each segment's exact prefix and returns true to stop early; the
+// segment's terms are t[seg_base ..] (entries past `len` count as zero: no running sum moves there).  Returns the exact running sum
+// after the last segment walked.
 constexpr int kSegBlen = 16;
-constexpr int kSegFloats = kSampThreads * kSegBlen;      // 64 KiB of LDS (8- and 32-term blocks measured: +25-30 us per draw)
+constexpr int kSegFloats = kSampThreads * kSegBlen;
 template <class Visit>
-__device__ __forceinline__ float wg_walk_segments(const float* t, int len, float init, float* seg, float* xch, float* carry_lds,
+__device__ __forceinline__ float wg_walk_segments(const float* t, int len, float init, float* xch, float* carry_lds,
                                                   int* rounds_out, Visit&& visit) {
     const int j = threadIdx.x;
     float carry = init;
     int rounds_total = 0;
-    for (int base = 0; base < len; base += kSegFloats) {
-        __syncthreads();                                  // the previous segment's readers are done
+    v4f cur[kSegBlen / 4], nx[kSegBlen / 4];
+    auto request = [&](v4f (&dst)[kSegBlen / 4], int base) {
 #pragma unroll
         for (int u = 0; u < kSegBlen / 4; ++u) {
-            const int q = j + u * kSampThreads;           // float4 index inside the segment (coalesced)
-            const int i = base + 4 * q;
+            const int i = base + kSegBlen * j + 4 * u;
             v4f v = {0.f, 0.f, 0.f, 0.f};
             if (i + 3 < len) v = *(const v4f*)(t + i);
             else {
@@ -186,12 +188,17 @@ __device__ __forceinline__ float wg_walk_segments(const float* t, int len, float
                 if (i + 1 < len) v.y = t[i + 1];
                 if (i + 2 < len) v.z = t[i + 2];
             }
-            ((v4f*)seg)[q] = v;
+            dst[u] = v;
         }
-        __syncthreads();
+    };
+    request(nx, 0);
+    for (int base = 0; base < len; base += kSegFloats) {
+#pragma unroll
+        for (int u = 0; u < kSegBlen / 4; ++u) cur[u] = nx[u];
+        if (base + kSegFloats < len) request(nx, base + kSegFloats);
         float in_j, out_j;
         int r = 0;
-        wg_exact_prefix(seg, kSegBlen, carry, xch, in_j, out_j, j == 0 ? &r : nullptr);
+        wg_exact_prefix(cur, carry, xch, in_j, out_j, j == 0 ? &r : nullptr);
         rounds_total += r;
         const bool stop = visit(base, in_j, out_j);
         __syncthreads();
@@ -341,7 +348,7 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a_in) 
     }
     // ---- exact sum in index order, p = e * (1/sum)                                  layers.rs:502-505
     __syncthreads();
-    const float esum = wg_walk_segments(a.probs, n, -0.0f, seg, xch, &carry_lds, &ss->rounds[0],   // Iterator::sum from -0.0
+    const float esum = wg_walk_segments(a.probs, n, -0.0f, xch, &carry_lds, &ss->rounds[0],   // Iterator::sum from -0.0
                                         [](int, float, float) { return false; });
     inv = 1.0f / esum;
     SAMP_STAMP(1);
@@ -366,9 +373,9 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a_in) 
     if (topp <= 0.0f || topp >= 1.0f) {
         // ---- sample_mult: first i with coin < cdf_i, cdf from 0.0                 sampler.rs:62-71
         int hit = -1;
-        wg_walk_segments(a.probs, n, 0.0f, seg, xch, &carry_lds, &ss->rounds[1], [&](int base, float in_j, float out_j) {
+        wg_walk_segments(a.probs, n, 0.0f, xch, &carry_lds, &ss->rounds[1], [&](int base, float in_j, float out_j) {
             float cum;
-            const int h = wg_first_crossing(seg, kSegBlen, in_j, out_j, coin, red, &cum);
+            const int h = wg_first_crossing(a.probs + base, kSegBlen, in_j, out_j, coin, red, &cum);
             if (h >= 0) hit = base + h;
             return h >= 0;
         });
@@ -493,10 +500,10 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a_in) 
             // cumulative probability in sorted order, truncation point, then the cdf walk with r = coin * cumulative
             int last_idx = -1;
             float cumulative = 0.0f;
-            const float total = wg_walk_segments(a.sp, n0, 0.0f, seg, xch, &carry_lds, &ss->rounds[2 + attempt],
+            const float total = wg_walk_segments(a.sp, n0, 0.0f, xch, &carry_lds, &ss->rounds[2 + attempt],
                                                  [&](int base, float in_j, float out_j) {
                 float cum;
-                const int h = wg_first_crossing(seg, kSegBlen, in_j, out_j, topp, red, &cum);   // first cum > topp
+                const int h = wg_first_crossing(a.sp + base, kSegBlen, in_j, out_j, topp, red, &cum);   // first cum > topp
                 if (h >= 0) { last_idx = base + h; cumulative = cum; }
                 return h >= 0;
             });
@@ -506,9 +513,9 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a_in) 
             if (!crossed) { last_idx = n0 - 1; cumulative = total; }
             const float r = coin * cumulative;
             hit = -1;
-            wg_walk_segments(a.sp, last_idx + 1, 0.0f, seg, xch, &carry_lds, nullptr, [&](int base, float in_j, float out_j) {
+            wg_walk_segments(a.sp, last_idx + 1, 0.0f, xch, &carry_lds, nullptr, [&](int base, float in_j, float out_j) {
                 float cum;
-                const int h = wg_first_crossing(seg, kSegBlen, in_j, out_j, r, red, &cum);       // first r < cdf
+                const int h = wg_first_crossing(a.sp + base, kSegBlen, in_j, out_j, r, red, &cum);       // first r < cdf
                 if (h >= 0) hit = base + h;
                 return h >= 0;
             });
@@ -519,6 +526,7 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(const SampleArgs a_in) 
     }
     SAMP_STAMP(7);
 #ifdef Q3_DEV
+    if (a_in.stamps != nullptr && tid == 0) a_in.stamps[10] = (unsigned long long)(unsigned)ss->rounds[0];
     if (a_in.stamps != nullptr && tid == 0) a_in.stamps[8] = (unsigned long long)(topp > 0.0f && topp < 1.0f ? 1 : 0);
 #endif
     if (tid == 0) {
