@@ -257,6 +257,25 @@ def test_attention_split_path_every_exact_sum_block_length(ops, oracle):
         assert_biteq(k2.reshape(S, kvd)[pos], rk.reshape(S, kvd)[pos], f"K row at position {pos}")
 
 
+@pytest.mark.parametrize("pos", [40, 100, 200, 700, 2300])
+def test_attention_scores_outside_the_exp_main_range(ops, oracle, pos):
+    """Norm weights of 6 put score differences far beyond 88 into the softmax: the exps of the attention kernels take glibc's main path
+    alone only when every lane of a wave is inside |x| < 88 (q3_expf_special), and fall back to the full special-case handling otherwise
+    -- underflow to +0, the subnormal tail -- bit for bit (short-context kernel: positions < 256; split path beyond)."""
+    nh, nkv, hd, S = 4, 2, 128, 4096
+    rng = np.random.default_rng(5)
+    kvd = nkv * hd
+    q = rng.standard_normal(nh * hd).astype(np.float32)
+    K = rng.standard_normal((S, kvd)).astype(np.float32)
+    V = rng.standard_normal((S, kvd)).astype(np.float32)
+    qw = np.full(hd, 6.0, np.float32)
+    kw = np.full(hd, 6.0, np.float32)
+    rb, _, _ = oracle.attention(q, K, V, qw, kw, pos, nh, nkv, hd)
+    xb, _, _ = ops.attention(q, K, V, qw, kw, pos, nh, nkv, hd, strict=True)
+    assert np.isfinite(rb).all()
+    assert_biteq(xb, rb, f"xb at position {pos}")
+
+
 def test_eager_launch_mode_matches_graph(q3):
     """Q3_FLAG_NO_GRAPH launches the same kernel chain eagerly: identical logits and tokens."""
     path = golden_path("tiny-untied.bin")
