@@ -88,8 +88,10 @@ const GemvCfg kGemvCfgs[] = {
     Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 512, 2, 4, 1, 0),
     Q3_ALT(Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 1024, 1, 2, 1, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 1024, 4, 2, 1, 0),
            Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 256, 4, 4, 1, 0))
-    Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 1024, 4, 2, 3, 0),
-    Q3_ALT(Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 512, 4, 2, 3, 1), Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 512, 4, 2, 3, 0))
+    // (r05 re-sweep on the 4B shape, six alternations on one box: 8-wave workgroups 1,367 vs 1,387 us per token at 32 tokens, 2,148 vs
+    // 2,164 at position 2,300 -- the 16-wave form had won in r04, before the attention and prologue changes of this round)
+    Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 512, 4, 2, 3, 0),
+    Q3_ALT(Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 512, 4, 2, 3, 1), Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 1024, 4, 2, 3, 0))
     Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 1024, 4, 2, 4, 0),
     Q3_ALT(Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 512, 4, 2, 4, 1), Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 512, 4, 2, 4, 0))
     // (r04: a 12-wave PF = 1 form still spills 92 B at 4096 and ran at 30.4 us; 2560: 16.5 vs 12.6 us -- not kept)
