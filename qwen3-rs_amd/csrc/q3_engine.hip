@@ -177,7 +177,9 @@ int env_int(const char* name, int dflt) {
 // block of x, 0 = program order only.  r03 A/B in reference-order mode (tools/gen_loop.py, Q3_STRICT=1): the barrier costs the QKV
 // launch 0.15 us at every shape (0.6B: 1,572 -> 1,527 tok/s), gains W13 0.4 us at dim 1024 (+0.3 %) and nothing at 2560 / 4096;
 // in Q3_FLAG_FAST mode (no exact sum in front of the quantizer) it is worth +6 % on the 0.6B shape.
-int xfirst_dflt(int wgt) { return wgt >= 1024 ? dev_knob("Q3_XFIRST_DEFAULT", 2) : 0; }
+// r05 re-sweep: only the 16-wave forms still carried the barrier (8B QKV / W1|W3): 1,895.7 with it vs 1,885.9 us per token without
+// (three alternations) -- off everywhere in reference-order mode now; the developer switch keeps the form for the FAST-mode A/B.
+int xfirst_dflt(int wgt) { return wgt >= 1024 ? dev_knob("Q3_XFIRST_DEFAULT", 0) : 0; }
 
 
 }  // namespace
