@@ -152,8 +152,45 @@ def test_cli_export_writes_checkpoint_and_tokenizer(q3, tmp_path):
     assert r.returncode == 1 and "does not exist" in r.stderr
 
 
+def cpp_cli():
+    """qwen3-rs_amd/q3_cli (make -C qwen3-rs_amd cli): `qwen3 inference` in C++ over the C ABI"""
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "qwen3-rs_amd"), "cli"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return os.path.join(ROOT, "qwen3-rs_amd", "q3_cli")
+
+
+def test_cpp_cli_tokenizer_matches_the_python_one(q3, tmp_path):
+    """The C++ command line carries its own tokenizer (tokenizer.rs:28-237 again): same ids and same bytes as tokenizer.py on the
+    fixture vocabulary -- merges, special tokens, a multi-byte character, an unknown character, a truncated file."""
+    from qwen3_rs_amd import tokenizer as tk
+    d = str(tmp_path)
+    n = make_tokenizer_json(d)
+    path = os.path.join(d, "model.bin")
+    out = tk.export_tokenizer(d, path, 7, 9)
+    open(path + ".template", "w").write("<|im_start|>user\n%s<|im_end|>\n")
+    exe = cpp_cli()
+
+    def both(text):
+        t = tk.Tokenizer(path, n)
+        ids = t.encode(text)
+        r = subprocess.run([exe, "tokenize", path, str(n), text], capture_output=True, timeout=60)
+        assert r.returncode == 0, r.stderr.decode(errors="replace")
+        lines = [l for l in r.stdout.split(b"\n") if not l.startswith(b"Warning:")]
+        got = [int(x) for x in lines[0].split()]
+        assert got == ids, (text, got, ids)
+        assert b"\n".join(lines[1:]) == b"".join(t.decode_bytes(i) for i in ids), text
+
+    for text in ["hello world", "hello<|im_start|>hello<|im_end|>", "<notatoken> é!", "a<b", "héllo wörld <|im_end|", "x" * 40 + "<|im_end|>",
+                 "<|im_start|>user\nhello world<|im_end|>\n"]:
+        both(text)
+    raw = open(out, "rb").read()
+    open(out, "wb").write(raw[: len(raw) - 9])            # truncated file: empty trailing tokens (tokenizer.rs:55-80)
+    both("hello<|im_end|>")
+
+
 @pytest.mark.gpu
-def test_cli_inference_generate_and_chat_match_the_reference_loops(q3, oracle, tmp_path):
+@pytest.mark.parametrize("front_end", ["python", "cpp"])
+def test_cli_inference_generate_and_chat_match_the_reference_loops(q3, oracle, tmp_path, front_end):
     """`qwen3 inference` on the device (prefill, forward, sampler) prints what the reference's host loops
     (generation.rs:9-151) print when driven by the CPU restatement with the same seed."""
     from qwen3_rs_amd import tokenizer as tk
@@ -222,7 +259,7 @@ def test_cli_inference_generate_and_chat_match_the_reference_loops(q3, oracle, t
                 nxt = smp.sample(om.forward(nxt, pos)); pos += 1
         return out
 
-    cli = [sys.executable, "-m", "qwen3_rs_amd.cli", "inference", path]
+    cli = [sys.executable, "-m", "qwen3_rs_amd.cli", "inference", path] if front_end == "python" else [cpp_cli(), "inference", path]
     for temperature, topp in ((0.0, 0.9), (0.9, 0.8)):
         r = subprocess.run(cli + ["-m", "generate", "-i", "hello world", "-t", str(temperature), "-p", str(topp), "-s", "77", "-c", "40"],
                            env=env, capture_output=True, timeout=600)
