@@ -319,6 +319,14 @@ int main(int argc, char** argv) {
         out_bytes(line + "\n" + bytes);
         return 0;
     }
+    // (test hook: q3_cli render <checkpoint> <vocab_size> <pos> <system prompt or "-"> <user prompt> prints the rendered turn)
+    if (argc == 7 && strcmp(argv[1], "render") == 0) {
+        Tokenizer tok;
+        if (!tok.load(argv[2], atoi(argv[3]), false)) return 1;
+        const std::string sys = argv[5];
+        out_bytes(tok.render_prompt((size_t)atol(argv[4]), sys == "-" ? nullptr : &sys, argv[6]));
+        return 0;
+    }
     if (argc < 3 || strcmp(argv[1], "inference") != 0) {
         usage();
         return 1;

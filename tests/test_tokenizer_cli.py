@@ -183,6 +183,12 @@ def test_cpp_cli_tokenizer_matches_the_python_one(q3, tmp_path):
     for text in ["hello world", "hello<|im_start|>hello<|im_end|>", "<notatoken> é!", "a<b", "héllo wörld <|im_end|", "x" * 40 + "<|im_end|>",
                  "<|im_start|>user\nhello world<|im_end|>\n"]:
         both(text)
+    # prompt rendering (generation.rs:188-195): the system template only at position 0, every "%s" replaced
+    open(path + ".template.with-system", "w").write("<|im_start|>system\n%s<|im_end|>\n<|im_start|>assistant\n%s")
+    t = tk.Tokenizer(path, n)
+    for pos, system, user in [(0, None, "hi"), (0, "be brief", "hi there"), (5, "be brief", "hi"), (0, "", "")]:
+        r = subprocess.run([exe, "render", path, str(n), str(pos), "-" if system is None else system, user], capture_output=True, timeout=60)
+        assert r.returncode == 0 and r.stdout.decode() == t.render_prompt(pos, system, user), (pos, system, user, r.stdout)
     raw = open(out, "rb").read()
     open(out, "wb").write(raw[: len(raw) - 9])            # truncated file: empty trailing tokens (tokenizer.rs:55-80)
     both("hello<|im_end|>")
