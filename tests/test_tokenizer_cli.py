@@ -286,3 +286,34 @@ def test_cli_inference_generate_and_chat_match_the_reference_loops(q3, oracle, t
         want = ref_chat(["hello world", "hello again world"], temperature, 0.8, 5, 24)
         assert want.count(b"> ") == 3 and len(want) > 30
         assert r.stdout == want, ("chat wrap", temperature, r.stdout, want)
+
+
+@pytest.mark.gpu
+def test_cli_front_ends_agree_on_system_prompt_reasoning_and_one_shot_chat(q3, tmp_path):
+    """`-y` (system prompt at position 0), `-r 1` (the thinking templates), sampled generate: the C++ and the Python command line print
+    the same bytes (lib.rs:109-138, generation.rs:174-195)."""
+    from qwen3_rs_amd import tokenizer as tk
+    ck = q3.checkpoint
+    d = str(tmp_path)
+    n_vocab = make_tokenizer_json(d)
+    shape = ck.ModelShape(256, 384, 2, 4, 2, n_vocab + (16 - n_vocab % 16) % 16, 96, 64, True, 64)
+    path = os.path.join(d, "model.bin")
+    ck.write_synthetic_checkpoint(path, shape, seed=21)
+    tk.export_tokenizer(d, path, 1, 2)
+    for suffix, body in ((".template", "<|im_start|>%s<|im_end|>"), (".template.with-thinking", "<|im_start|>%s<|im_end|>hm"),
+                         (".template.with-system", "<|im_start|>world %s<|im_end|>"), (".template.with-system-and-thinking", "<|im_start|>hello %s<|im_end|>hm")):
+        open(path + suffix, "w").write(body)
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "qwen3-rs_amd"))
+    fronts = ([sys.executable, "-m", "qwen3_rs_amd.cli", "inference", path], [cpp_cli(), "inference", path])
+    # (chat without -i: the turns come from stdin and the loop ends at end of input; a one-shot `-i` chat on a model that never emits
+    # BOS / EOS feeds the prompt again at every wrap, forever -- generation.rs:65-69,174-188 -- so it is not run here)
+    for extra, stdin in ((["-m", "chat", "-y", "hello", "-r", "1", "-t", "0", "-c", "48"], b"hello world\n"),
+                         (["-m", "chat", "-y", "hello", "-t", "0.8", "-p", "0.7", "-s", "9", "-c", "48"], b"hello world\nhello\n"),
+                         (["-m", "chat", "-r", "1", "-t", "0.8", "-p", "1.0", "-s", "3", "-c", "32"], b"hello\n"),
+                         (["-m", "generate", "-i", "hello world hello", "-t", "1.2", "-p", "0.0", "-s", "11", "-c", "32"], b"")):
+        outs = []
+        for cli in fronts:
+            r = subprocess.run(cli + extra, env=env, capture_output=True, timeout=120, input=stdin)
+            assert r.returncode == 0, r.stderr.decode(errors="replace")
+            outs.append(r.stdout)
+        assert outs[0] == outs[1] and len(outs[0]) > 0, (extra, outs)
