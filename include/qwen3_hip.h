@@ -17,6 +17,19 @@
  *     Q3_PREFILL_M=<16..4096>   positions per weight pass of q3_prefill_batched (default 2048; <= 32 selects the batch-32
  *                               kernels).  The dense attention scratch grows with it: 4 * M * n_heads * context bytes.
  *     Q3_DEBUG_TIMING=1         host-side timing of q3_forward / q3_host_generate phases on stderr.
+ *
+ * Build options (qwen3-rs_amd/Makefile, `make abl EXTRA=-D... ABL=name` -> libq3_<name>.so; never part of libqwen3_hip.so):
+ *     -DQ3_TICKET_ACQ_REL       the classifier's last-arriver ticket (csrc/q3_gemv.h, EPI_LOGITS) with acquire + release ordering
+ *                               on its two device-scope read-modify-writes instead of relaxed.  The shipped library keeps
+ *                               them relaxed: every workgroup's fetch_max on the argmax cell and its fetch_add on the ticket
+ *                               are device-scope RMWs executed at the L2 / memory coherence point, and the ticket's operand
+ *                               DATA-DEPENDS on the maximum's return value, so the add cannot issue before the max has
+ *                               returned; the last arriver then reads the cell with another RMW.  That is an argument about
+ *                               gfx950 (RMWs are performed at one point of coherence, in issue order per address
+ *                               dependence), not about the HIP memory model, which would want release on the max and acquire
+ *                               on the ticket.  Measured cost of the ordered form: +1.4 ... +4.8 us per token
+ *                               (profiles/r05_ticket_order.txt: a release is a buffer_wbl2 in each of ~590 workgroups).
+ *                               Build it when porting to another target or toolchain.
  * Every other Q3_* switch of earlier rounds (kernel-form A/B, tile and workgroup overrides, ablation bits, in-kernel
  * timelines) exists only in the developer build, libqwen3_hip_dev.so (`make -C qwen3-rs_amd dev`, -DQ3_DEV), together with
  * the kernel forms that lost their A/B; results are identical in both builds.
@@ -68,6 +81,14 @@ typedef struct q3_engine q3_engine;
                            greedy tokens can differ from the CPU path.  The int8 group-quant matmul itself
                            is bit-exact in both modes. */
 #define Q3_FLAG_NO_GRAPH 2u /* launch kernels eagerly instead of replaying a captured hipGraph */
+#define Q3_FLAG_NO_VALUE_T 4u /* do not keep the TRANSPOSED copy of the value cache.  Reference-order engines whose context
+                           can reach the split attention path (seq_len > 256, a multiple of 4) keep the value cache twice:
+                           row-major [L][seq_len][kv_dim] and transposed [L][kv_dim][seq_len], n_layers * kv_dim * seq_len * 4
+                           bytes each (Qwen3-8B: 6.0 GB at 40,960 positions, 19.3 GB at 131,072; 0.6B: 4.7 GB at 40,960).
+                           The copy lets the long-context output kernel stream 1 KB runs instead of 64-byte pieces
+                           (config-3 decode 468 -> 503 tok/s when it went in).  With this flag the engine allocates the
+                           row-major cache only and the long-context kernel reads it (same results bit for bit).
+                           Q3_FLAG_FAST engines never allocate the copy (their output kernel does not read it). */
 
 /* ------------------------------------------------------------------------------------------------
  * 1. The reference surface

@@ -31,6 +31,22 @@
 //     the position's own round trip (rows past the context are valid cache rows: requested, never committed); the launch then
 //     has ONE dependent memory round trip in front of the tiles instead of two.
 // Dynamic LDS: max_t rows x (HD + 4) floats (attn_short2_smem_bytes): product tile [t][HD + 4]; value tile [t][HD] behind row 128.
+//
+// Barrier contract.  The wave roles meet a DIFFERENT number of s_barrier each, and staging waves end in the middle of the kernel:
+// the code relies on the gfx950 rule that a terminated wave no longer counts at its workgroup's s_barrier (and on LDS spin flags
+// -- vflag, bcount -- between waves of one workgroup).  That is outside the portable HIP barrier contract; it was validated on
+// gfx950 only (every tier boundary: test_attention_short_contexts_head_dim_128, product AND developer build), hence the #error.
+//   barriers each role meets, by context length np:
+//   role (waves)                       | np <= 64        | 64 < np <= 128   | np > 128
+//   q-norm / k-norm + score (0, 1)     | A', A, C        | A', A, C         | A', A, B, C
+//   staging + far score (2, 3)         | A', A, then END | A', A, then END  | A', A, B, C
+//   output (4, 5)                      | A', A, C        | A', A, C         | A', A, B, C
+//   staging only (6, 7)                | A', A, then END | A', A, then END  | A', A, then END
+//   (np <= 64: the staging waves commit the value tile BEHIND A, raise vflag and end; "barrier B" of a single score-wave pair is
+//   the LDS counter bcount; the second workgroup of grid (heads, 2) leaves before any barrier when np <= 64.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "k_attn_short2 relies on gfx950 s_barrier behaviour for terminated waves; validated on gfx950 only"
+#endif
 constexpr int kS2Threads = 512;
 constexpr int kS2MaxT = 256;
 __host__ __device__ inline size_t attn_short2_smem_bytes(int hd, int max_t) { return 4 * (size_t)max_t * (size_t)(hd + 4); }

@@ -250,6 +250,12 @@ struct q3_engine {
     int cmax_stride = 0;
     int att_stride = 0;
     int split_pos = 256;
+    // the transposed value cache exists iff the long-context output kernel will read it: reference-order mode (k_attn_out reads it
+    // only when strict), a context that reaches split_pos, rows of whole float4, and the caller did not opt out
+    bool wants_value_t() const {
+        return !(flags & (Q3_FLAG_FAST | Q3_FLAG_NO_VALUE_T)) && (cfg.seq_len % 4) == 0 && (int64_t)cfg.seq_len > (int64_t)split_pos &&
+               dev_knob("Q3_VALUE_T", 1) != 0;
+    }
     BatchCtx* batch = nullptr;                 // batched decode state (q3_batch_init), see q3_batch_host.inc
     // device-side Sampler (q3_sampler_set): temperature > 0 makes every token draw go through k_sample
     bool sampling = false;
@@ -602,8 +608,10 @@ int q3_engine::load(const char* path, uint32_t ctx_len) {
     HIP_TRY(hipMalloc((void**)&d_value, 4 * kv_elems));
     HIP_TRY(hipMemset(d_key, 0, 4 * kv_elems));
     HIP_TRY(hipMemset(d_value, 0, 4 * kv_elems));
-    // the long-context plan streams a transposed copy of the value rows (k_attn_out; contexts that can reach the split position only)
-    if ((S % 4) == 0 && S > dev_knob("Q3_ATT_SPLIT_POS", 256) && dev_knob("Q3_VALUE_T", 1)) {
+    // the long-context plan streams a transposed copy of the value rows (k_attn_out, strict mode only; contexts that can reach the
+    // split position only -- split_pos is set here, once, and build_plan uses the same value)
+    split_pos = dev_knob("Q3_ATT_SPLIT_POS", 256);
+    if (wants_value_t()) {
         HIP_TRY(hipMalloc((void**)&d_value_t, 4 * kv_elems));
         HIP_TRY(hipMemset(d_value_t, 0, 4 * kv_elems));
     }
@@ -646,7 +654,6 @@ int q3_engine::build_plan() {
     const int big_cap = dev_knob("Q3_WG_PER_CU_LMHEAD", 2);   // all workgroups resident at once (the NORM prologue keeps ~190 VGPRs live)
     const int att_lds_max = dev_knob("Q3_ATT_LDS_MAX", 4096);
 
-    split_pos = dev_knob("Q3_ATT_SPLIT_POS", 256);
     att_stride = (S + 255) & ~255;
     const int slice_w = attn_slice_w(hd, cfg.n_heads, n_cu);
     const int nsl = hd / slice_w;
@@ -1015,10 +1022,11 @@ int q3_engine::enqueue_forward(bool eager, size_t pos, bool draw) {
     if (graph_exec && !eager) {
         HIP_TRY(hipGraphLaunch(lng ? graph_long_exec : (rng >= 0 ? graph_rng_exec[rng] : graph_exec), stream));
     } else {
-        // (eager launches: the same row-request hint the captured range graphs carry, as long as the engine keeps range graphs at
-        // all -- an engine without a captured graph decides from the position alone)
+        // (eager launches: the same row-request hint the captured range graphs carry -- only when the engine keeps range graphs
+        // (developer build, Q3_ATT_RANGES=1): an eager launch is the SAME launch as the captured one, grid (heads, 2) included, so
+        // that eager rocprofv3 traces time the kernel shape the graph replays)
         int steps = 0;
-        if (!lng && (ranges || !graph_exec))
+        if (!lng && ranges)
             for (int i = kNRange - 1; i >= 0; --i)
                 if (pos < (size_t)(8 * kRangeSteps[i])) steps = kRangeSteps[i];
         for (const Launch& L : (lng ? plan_long : plan)) launch_one(L, this, false, steps);

@@ -7,10 +7,10 @@ the checkpoint format (qwen3-export/src/model_exporter.rs).  All compute runs in
 (hand-written HIP kernels); there is no CPU fallback -- loading fails loudly if the library is missing.
 """
 from .engine import (Q3Error, ModelConfig, Transformer, TransformerBuilder, lib_path, dev_lib_path, load_library, use_library, ops,
-                     FLAG_FAST, FLAG_NO_GRAPH, EXPORTED_SYMBOLS, source_build_id)
+                     FLAG_FAST, FLAG_NO_GRAPH, FLAG_NO_VALUE_T, EXPORTED_SYMBOLS, source_build_id)
 from .generation import generate, chat_turn, TokenMetrics, sample_argmax
 from . import checkpoint
 
 __all__ = ["Q3Error", "ModelConfig", "Transformer", "TransformerBuilder", "lib_path", "dev_lib_path", "load_library", "use_library", "ops",
-           "FLAG_FAST", "FLAG_NO_GRAPH", "EXPORTED_SYMBOLS", "source_build_id", "generate", "chat_turn", "TokenMetrics",
+           "FLAG_FAST", "FLAG_NO_GRAPH", "FLAG_NO_VALUE_T", "EXPORTED_SYMBOLS", "source_build_id", "generate", "chat_turn", "TokenMetrics",
            "sample_argmax", "checkpoint"]

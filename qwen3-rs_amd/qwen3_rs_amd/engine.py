@@ -10,6 +10,7 @@ import numpy as np
 
 FLAG_FAST = 1
 FLAG_NO_GRAPH = 2
+FLAG_NO_VALUE_T = 4
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _DIST_DIR = os.path.dirname(_PKG_DIR)
@@ -372,6 +373,12 @@ class TransformerBuilder:
     def with_strict(self, strict: bool = True) -> "TransformerBuilder":
         """strict (default): reference summation order, bit-identical logits.  False: tree reductions."""
         self.flags = (self.flags & ~FLAG_FAST) if strict else (self.flags | FLAG_FAST)
+        return self
+
+    def with_value_transposed(self, keep: bool = True) -> "TransformerBuilder":
+        """keep (default): contexts past 256 positions hold the value cache twice (row-major + transposed, include/qwen3_hip.h
+        Q3_FLAG_NO_VALUE_T has the byte counts).  False: the row-major cache only; same results, slower long-context decode."""
+        self.flags = (self.flags & ~FLAG_NO_VALUE_T) if keep else (self.flags | FLAG_NO_VALUE_T)
         return self
 
     def with_graph(self, graph: bool = True) -> "TransformerBuilder":

@@ -450,8 +450,15 @@ def test_long_context_split_attention_vs_oracle(q3, oracle, tmp_ckpt_dir):
             ot = oracle.sample_argmax(om.forward(ot, p))
             want.append(ot)
         assert t.generate_greedy(11, 250, 12) == want
-    with q3.TransformerBuilder(path).with_strict(False).build() as t:      # opt-in tree mode through the split path
+    with q3.TransformerBuilder(path).with_value_transposed(False).build() as t:   # Q3_FLAG_NO_VALUE_T: row-major value cache only
         om.reset()
+        tok = 7
+        for pos in [0, 255, 256, 257, 384, 700, 2047, 300]:
+            a, b = np.array(t.forward(tok, pos), copy=True), om.forward(tok, pos)
+            assert_biteq(a, b, f"no transposed value cache, pos {pos}")
+            tok = oracle.sample_argmax(b)
+    with q3.TransformerBuilder(path).with_strict(False).build() as t:      # opt-in tree mode through the split path
+        om.reset()                                                          # (never allocates the transposed value cache)
         for pos in (300, 301, 900):
             a, b = np.array(t.forward(3, pos), copy=True), om.forward(3, pos)
             assert np.max(np.abs(a - b)) <= 2e-5

@@ -1,6 +1,7 @@
 """CPU tests of the product's host side: the C-ABI library loads and exports every symbol the header
 declares, fails loudly without a GPU, never routes through the oracle, and the host mirrors of the
 reference's call patterns behave like generation.rs."""
+import json
 import os
 import re
 import subprocess
@@ -279,6 +280,28 @@ def test_host_sample_argmax_last_maximum_under_total_order(q3):
         assert lib.q3_host_sample_argmax(a.ctypes.data_as(fp), a.size, None) == want
 
 
+def _two_replica_bench_check(extra):
+    """Body shared by the CPU (stub engine) and the two-GPU (real engines) variants: `bench.py --gpus 2` is ONE line with
+    n_gpus 2 whose whole-job value is (well above) one replica's."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "2", "--no-cpu-baseline",
+           "--no-other-configs"] + list(extra)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 16 and d["scaling"] == "weak"
+    one = subprocess.run(cmd[:3] + ["1"] + cmd[4:], capture_output=True, text=True, timeout=1200)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d1["n_gpus"] == 1
+    return d, d1
+
+
+def test_bench_two_replicas_stub_engine_same_body_as_the_two_gpu_test():
+    """The body of the two-GPU test below, on the launcher's host stub: a test that only ever skips must not be able to rot."""
+    d, d1 = _two_replica_bench_check(["--stub-engine"])
+    assert d["value"] > 1.5 * d1["value"], (d["value"], d1["value"])
+
+
 @pytest.mark.gpu
 def test_bench_two_real_replicas_on_two_devices():
     """`bench.py --gpus 2` with REAL engines: one process + one engine per GPU (devices 0 and 1), no collective on the data
@@ -286,12 +309,102 @@ def test_bench_two_real_replicas_on_two_devices():
     import torch
     if torch.cuda.device_count() < 2:          # (counting devices does not initialise HIP in this process)
         pytest.skip("fewer than two GPUs visible")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "2", "--no-cpu-baseline",
-           "--no-other-configs"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200)
-    assert r.returncode == 0, r.stderr[-2000:]
-    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert d["n_gpus"] == 2 and d["steps"] == 16 and d["scaling"] == "weak"
-    one = subprocess.run(cmd[:3] + ["1"] + cmd[4:], capture_output=True, text=True, timeout=1200)
-    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    d, d1 = _two_replica_bench_check([])
     assert d["value"] > 1.5 * d1["value"], (d["value"], d1["value"])      # two independent replicas: ~2x, never ~1x
+
+
+def _undefined_names(path):
+    """Names a module reads at function or module level that nothing binds: pyflakes when importable, else an ast walk
+    (module-level bindings + builtins + each function's own parameters / assignments / imports / comprehension targets)."""
+    import ast
+    import builtins
+    src = open(path).read()
+    compile(src, path, "exec")                                             # syntax
+    try:
+        from pyflakes import api, reporter
+        import io
+        out, err = io.StringIO(), io.StringIO()
+        api.check(src, path, reporter.Reporter(out, err))
+        return [ln for ln in out.getvalue().splitlines() if "undefined name" in ln]
+    except ImportError:
+        pass
+    tree = ast.parse(src, path)
+    bound = set(dir(builtins)) | {"__file__", "__name__", "__doc__", "__builtins__", "__spec__", "__package__"}
+    for node in ast.walk(tree):                                            # anything bound anywhere in the file, by any construct
+        if isinstance(node, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)):
+            bound.add(node.name)
+            if not isinstance(node, ast.ClassDef):
+                a = node.args
+                for arg in a.posonlyargs + a.args + a.kwonlyargs + ([a.vararg] if a.vararg else []) + ([a.kwarg] if a.kwarg else []):
+                    bound.add(arg.arg)
+        elif isinstance(node, ast.Lambda):
+            a = node.args
+            for arg in a.posonlyargs + a.args + a.kwonlyargs + ([a.vararg] if a.vararg else []) + ([a.kwarg] if a.kwarg else []):
+                bound.add(arg.arg)
+        elif isinstance(node, (ast.Import, ast.ImportFrom)):
+            for al in node.names:
+                bound.add((al.asname or al.name).split(".")[0])
+        elif isinstance(node, ast.Name) and isinstance(node.ctx, (ast.Store, ast.Del)):
+            bound.add(node.id)
+        elif isinstance(node, ast.ExceptHandler) and node.name:
+            bound.add(node.name)
+        elif isinstance(node, (ast.Global, ast.Nonlocal)):
+            bound.update(node.names)
+    # a name imported only INSIDE one function does not exist in another: per-function check of module-like names
+    module_level = set(dir(builtins)) | {"__file__", "__name__", "__doc__", "__spec__", "__package__"}
+    for node in tree.body:
+        for sub in ast.walk(node) if not isinstance(node, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)) else [node]:
+            if isinstance(sub, (ast.Import, ast.ImportFrom)):
+                for al in sub.names:
+                    module_level.add((al.asname or al.name).split(".")[0])
+            elif isinstance(sub, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)):
+                module_level.add(sub.name)
+            elif isinstance(sub, ast.Name) and isinstance(sub.ctx, ast.Store):
+                module_level.add(sub.id)
+    bad = []
+
+    def visit_fn(fn, outer):
+        local = set(outer)
+        for sub in ast.walk(fn):
+            if isinstance(sub, (ast.Import, ast.ImportFrom)):
+                for al in sub.names:
+                    local.add((al.asname or al.name).split(".")[0])
+            elif isinstance(sub, ast.Name) and isinstance(sub.ctx, (ast.Store, ast.Del)):
+                local.add(sub.id)
+            elif isinstance(sub, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)):
+                local.add(sub.name)
+            elif isinstance(sub, ast.ExceptHandler) and sub.name:
+                local.add(sub.name)
+            elif isinstance(sub, (ast.Global, ast.Nonlocal)):
+                local.update(sub.names)
+            elif isinstance(sub, ast.arg):
+                local.add(sub.arg)
+        for sub in ast.walk(fn):
+            if isinstance(sub, ast.Name) and isinstance(sub.ctx, ast.Load) and sub.id not in local:
+                bad.append(f"{path}:{sub.lineno}: undefined name '{sub.id}'")
+
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Name) and isinstance(node.ctx, ast.Load) and node.id not in bound:
+            bad.append(f"{path}:{node.lineno}: undefined name '{node.id}'")
+    for node in tree.body:
+        if isinstance(node, (ast.FunctionDef, ast.AsyncFunctionDef)):
+            visit_fn(node, module_level)
+        elif isinstance(node, ast.ClassDef):
+            for m in node.body:
+                if isinstance(m, (ast.FunctionDef, ast.AsyncFunctionDef)):
+                    visit_fn(m, module_level | {node.name})
+    return sorted(set(bad))
+
+
+def test_python_sources_compile_and_have_no_undefined_names():
+    """tests/*.py, tools/*.py, bench.py, __graft_entry__.py and the package byte-compile and read no name that nothing binds
+    (the two-GPU test of round 5 called json.loads in a module that never imported json and only ever skipped)."""
+    import glob
+    files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    for pat in ("tests/*.py", "tests/golden/*.py", "tools/*.py", "oracle/*.py", "qwen3-rs_amd/qwen3_rs_amd/*.py"):
+        files += sorted(glob.glob(os.path.join(ROOT, pat)))
+    assert len(files) > 10
+    bad = []
+    for f in files:
+        bad += _undefined_names(f)
+    assert not bad, "\n".join(bad)
