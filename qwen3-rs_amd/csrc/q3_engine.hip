@@ -147,7 +147,7 @@ namespace q3inst {
 typedef void (*GemvFn)(const q3::GemvArgs);
 struct GemvCfg { int pro, epi, n, wgt, ept, ru, ju, pf; GemvFn fn; };
 GemvFn gemv_pick(int pro, int epi, int G, int RU, int JU, int FIN, int PF);       // generic run-time-n kernels
-const GemvCfg* find_cfg(int pro, int epi, int n, int G, int which);              // shape-specialised kernels
+const GemvCfg* find_cfg(int pro, int epi, int n, int G, int which, bool fast = false);              // shape-specialised kernels
 }
 using q3inst::GemvCfg;
 using q3inst::find_cfg;
@@ -650,6 +650,7 @@ int q3_engine::build_plan() {
     const int dim = cfg.dim, L = cfg.n_layers, hd = cfg.head_dim, V = cfg.vocab_size, H = cfg.hidden_dim;
     const int G = cfg.group_size, ahd = cfg.n_heads * hd, kvd = cfg.n_kv_heads * hd, S = cfg.seq_len;
     const int strict = (flags & Q3_FLAG_FAST) ? 0 : 1;
+    const bool fast_fold = !strict && dev_knob("Q3_FAST_FOLD", 1) != 0;   // tolerance mode: tree fold of the GEMV group terms too
     const int small_cap = dev_knob("Q3_WG_PER_CU_SMALL", 2);   // two workgroups per CU: half the rows (and fold chains) per wave
     const int big_cap = dev_knob("Q3_WG_PER_CU_LMHEAD", 2);   // all workgroups resident at once (the NORM prologue keeps ~190 VGPRs live)
     const int att_lds_max = dev_knob("Q3_ATT_LDS_MAX", 4096);
@@ -714,7 +715,7 @@ int q3_engine::build_plan() {
             }
             a.norm_w = rms_att + (size_t)l * dim;
             a.in = d_x;
-            const GemvCfg* cfg = find_cfg(l == 0 ? PRO_EMBED_NORM : PRO_NORM, EPI_QKV, dim, G, dev_knob("Q3_CFG_QKV", 0));
+            const GemvCfg* cfg = find_cfg(l == 0 ? PRO_EMBED_NORM : PRO_NORM, EPI_QKV, dim, G, dev_knob("Q3_CFG_QKV", 0), fast_fold);
             if (cfg && (hd % cfg->ru) != 0) cfg = nullptr;           // batches must not straddle the q|k|v segments
             if (l == 0) {
                 a.emb_q = tok.q;
@@ -773,7 +774,7 @@ int q3_engine::build_plan() {
                 if ((rc = set_attn_short_smem(Ln.aa))) return rc;
             }
             // k_attn_short can hand Wo its operand quantized (qwen3.rs:152 fused into the attention epilogue)
-            wo_preq = Ln.attn_kind == 3 ? find_cfg(PRO_PREQR, EPI_RESID, ahd, G, dev_knob("Q3_CFG_WO", 0)) : nullptr;
+            wo_preq = Ln.attn_kind == 3 ? find_cfg(PRO_PREQR, EPI_RESID, ahd, G, dev_knob("Q3_CFG_WO", 0), fast_fold) : nullptr;
             if (wo_preq) {
                 Ln.aa.xbq = d_xbq;
                 Ln.aa.xbs = d_xbs;
@@ -793,7 +794,7 @@ int q3_engine::build_plan() {
             // quantize-in-prologue form: the long-context plan always, the short plan when attention emits no int8
             Launch Lq = Ln;
             GemvArgs aq = a;
-            if (const GemvCfg* cq = find_cfg(PRO_QUANT, EPI_RESID, ahd, G, dev_knob("Q3_CFG_WO_LONG", 0))) {
+            if (const GemvCfg* cq = find_cfg(PRO_QUANT, EPI_RESID, ahd, G, dev_knob("Q3_CFG_WO_LONG", 0), fast_fold)) {
                 apply_cfg(Lq, aq, *cq, dim, n_cu);
             } else {
                 const GemvShape gs = plan_gemv(dim, ahd, G, false, 1, n_cu, small_cap);
@@ -825,7 +826,7 @@ int q3_engine::build_plan() {
             a.total_rows = 2 * H;
             a.norm_w = rms_ffn + (size_t)l * dim;
             a.in = d_x;
-            if (const GemvCfg* cfg = find_cfg(PRO_NORM, EPI_SWIGLU, dim, G, dev_knob("Q3_CFG_W13", 0))) {
+            if (const GemvCfg* cfg = find_cfg(PRO_NORM, EPI_SWIGLU, dim, G, dev_knob("Q3_CFG_W13", 0), fast_fold)) {
                 a.xfirst = dev_knob("Q3_XFIRST_W13", dim < 2048 ? xfirst_dflt(cfg->wgt) : 0);
                 apply_cfg(Ln, a, *cfg, H, n_cu);
             } else {
@@ -848,7 +849,7 @@ int q3_engine::build_plan() {
             a.seg[0] = Seg{w2[lw].q, w2[lw].s, d_x, dim, 0};
             a.total_rows = dim;
             a.in = d_hb;
-            if (const GemvCfg* cfg = find_cfg(PRO_QUANT, EPI_RESID, H, G, dev_knob("Q3_CFG_W2", 0))) {
+            if (const GemvCfg* cfg = find_cfg(PRO_QUANT, EPI_RESID, H, G, dev_knob("Q3_CFG_W2", 0), fast_fold)) {
                 a.xfirst = dev_knob("Q3_XFIRST_W2", 0);
                 apply_cfg(Ln, a, *cfg, dim, n_cu);
             } else {
@@ -875,7 +876,7 @@ int q3_engine::build_plan() {
         a.in = d_x;
         a.tap_out = d_tap;
         GemvShape gs = plan_gemv(V, dim, G, false, 1, n_cu, big_cap, false);
-        const GemvCfg* lcfg = find_cfg(PRO_NORM, EPI_LOGITS, dim, G, dev_knob("Q3_CFG_LMHEAD", 0));
+        const GemvCfg* lcfg = find_cfg(PRO_NORM, EPI_LOGITS, dim, G, dev_knob("Q3_CFG_LMHEAD", 0), fast_fold);
         if (lcfg) {
             a.xfirst = dev_knob("Q3_XFIRST_LM", 0);
             apply_cfg(Ln, a, *lcfg, V, n_cu);

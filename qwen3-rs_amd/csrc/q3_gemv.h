@@ -1081,7 +1081,7 @@ __device__ __forceinline__ float ordered_row_sum(const float* t, int ng) {
 template <int PRO, int EPI, int LPG_T, int RU, int JU, int FIN = 0, int PF = 0, int N_T = 0, int WGT = kWG, int EPT = 4>
 __global__ __launch_bounds__(WGT) void k_gemv(const GemvArgs a) {
     static_assert(N_T > 0 || (WGT == kWG && EPT == 4), "the generic prologue is written for 256 threads");
-    static_assert(N_T == 0 || (LPG_T == 4 && FIN == 1), "specialised shapes: group 64, register fold");
+    static_assert(N_T == 0 || (LPG_T == 4 && FIN >= 1), "specialised shapes: group 64, register fold");
     static_assert(PRO != PRO_PREQR || (N_T > 0 && (N_T + 1023) / 1024 == JU), "register-direct xq: one tile per row");
     constexpr int WAVES = WGT / 64;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1276,6 +1276,21 @@ __global__ __launch_bounds__(WGT) void k_gemv(const GemvArgs a) {
                     t[r] = t[r] * xsc;
                     t[r] = cok ? t[r] : 0.0f;
                     acc[r] = racc[r] + t[r];
+                }
+                if constexpr (FIN == 2) {
+                    // tolerance mode (Q3_FLAG_FAST): the chunk's 16 group terms as a wavefront TREE -- two mirror steps inside the
+                    // 16-lane rows (a term already sits in the 4 lanes of its group), two row broadcasts; the chunk total of lane
+                    // 63 joins the running row sum.  4 hops instead of 15; NOT the reference's order (tensor.rs:53-60).
+#pragma unroll
+                    for (int r = 0; r < RU; ++r) {
+                        float v = t[r];
+                        v += dpp_f<0x141>(v);
+                        v += dpp_f<0x140>(v);
+                        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));
+                        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));
+                        racc[r] = racc[r] + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+                    }
+                    continue;
                 }
                 // ascending-group fold as a chain of DPP adds: group g's running sum lives in lane 4g+3 and moves to lane
                 // 4g+7 by row_shr:4 (row_bcast:15 across the 16-lane rows); lane 63 ends with the chunk's sum.  A hop

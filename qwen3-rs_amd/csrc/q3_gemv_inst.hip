@@ -63,7 +63,7 @@ namespace {
 // other group sizes) takes the generic path.
 // ------------------------------------------------------------------------------------------------
 #define Q3_CFG(PRO, EPI, N, WGT, EPT, RU, JU, PF) \
-    {PRO, EPI, N, WGT, EPT, RU, JU, PF, (GemvFn)k_gemv<PRO, EPI, 4, RU, JU, 1, PF, N, WGT, EPT>}
+    {PRO, EPI, N, WGT, EPT, RU, JU, PF, (GemvFn)k_gemv<PRO, EPI, 4, RU, JU, Q3_CFG_FIN, PF, N, WGT, EPT>}
 #define Q3_CFG_NORM_QKV(N, WGT, EPT, RU, JU, PF) Q3_CFG(PRO_NORM, EPI_QKV, N, WGT, EPT, RU, JU, PF), Q3_CFG(PRO_EMBED_NORM, EPI_QKV, N, WGT, EPT, RU, JU, PF)
 // The first entry of a role is what the product runs.  The other candidates of a role (the forms that lost their A/B; they stay
 // selectable through Q3_CFG_<FAMILY>=k for re-sweeps) exist in the developer build only: Q3_ALT(...).
@@ -72,61 +72,80 @@ namespace {
 #else
 #define Q3_ALT(...)
 #endif
-const GemvCfg kGemvCfgs[] = {
-    // --- QKV: RMSNorm_att + quantize + wq|wk|wv
-    // (dim 1024, end of r03: the 512-thread / two-rows-per-wave forms lead the 1024-thread ones by 0.1 us per launch since the
-    // wave-0 block loads go through LDS; same-process A/B of the three 0.6B changes below: 1,552-1,567 -> 1,582-1,599 tok/s)
-    Q3_CFG_NORM_QKV(1024, 512, 2, 2, 1, 0),
-    Q3_ALT(Q3_CFG_NORM_QKV(1024, 1024, 1, 1, 1, 0), Q3_CFG_NORM_QKV(1024, 1024, 4, 1, 1, 0), Q3_CFG_NORM_QKV(1024, 256, 4, 2, 1, 0))
-    // (r04 sweep, 4B: 12 waves x 2 rows = 6,144 rows exactly, 6.18 vs 6.56 us; the same form at 4096 is slower, 8.33 vs 7.94 us)
-    Q3_CFG_NORM_QKV(2560, 768, 4, 2, 3, 0),
-    Q3_ALT(Q3_CFG_NORM_QKV(2560, 1024, 4, 1, 3, 0), Q3_CFG_NORM_QKV(2560, 1024, 4, 1, 3, 1), Q3_CFG_NORM_QKV(2560, 1024, 4, 2, 3, 0))
-    Q3_CFG_NORM_QKV(4096, 1024, 4, 1, 4, 0),
-    // (r04) 12-wave workgroups: 6,144 rows = 3,072 waves x 2 rows, every byte of the launch requested at kernel entry
-    Q3_ALT(Q3_CFG_NORM_QKV(4096, 1024, 4, 1, 4, 1), Q3_CFG_NORM_QKV(4096, 1024, 4, 2, 4, 0), Q3_CFG_NORM_QKV(4096, 768, 4, 2, 4, 0))
-    // --- W1|W3 + SwiGLU
-    Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 512, 2, 4, 1, 0),
-    Q3_ALT(Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 1024, 1, 2, 1, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 1024, 4, 2, 1, 0),
-           Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 256, 4, 4, 1, 0))
-    // (r05 re-sweep on the 4B shape, six alternations on one box: 8-wave workgroups 1,367 vs 1,387 us per token at 32 tokens, 2,148 vs
-    // 2,164 at position 2,300 -- the 16-wave form had won in r04, before the attention and prologue changes of this round)
-    Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 512, 4, 2, 3, 0),
-    Q3_ALT(Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 512, 4, 2, 3, 1), Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 1024, 4, 2, 3, 0))
-    Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 1024, 4, 2, 4, 0),
-    Q3_ALT(Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 512, 4, 2, 4, 1), Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 512, 4, 2, 4, 0))
-    // (r04: a 12-wave PF = 1 form still spills 92 B at 4096 and ran at 30.4 us; 2560: 16.5 vs 12.6 us -- not kept)
-    // --- Wo behind the short-context attention kernel (xb arrives quantized): register-direct activation
-    Q3_CFG(PRO_PREQR, EPI_RESID, 2048, 256, 4, 1, 2, 0),
-    Q3_ALT(Q3_CFG(PRO_PREQR, EPI_RESID, 2048, 512, 4, 1, 2, 0))
-    Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 256, 4, 1, 4, 0),
-    Q3_ALT(Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 256, 4, 2, 4, 0), Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 512, 4, 1, 4, 0),
-           Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 1024, 4, 1, 4, 0))
-    // --- quantize + W2 (and Wo of the long-context plan)
-    Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 256, 4, 1, 3, 0),
-    Q3_ALT(Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 512, 4, 1, 3, 0), Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 1024, 4, 1, 3, 0))
-    Q3_CFG(PRO_QUANT, EPI_RESID, 9728, 1024, 4, 1, 2, 1),
-    Q3_ALT(Q3_CFG(PRO_QUANT, EPI_RESID, 9728, 512, 4, 1, 2, 1))
-    Q3_CFG(PRO_QUANT, EPI_RESID, 12288, 1024, 4, 1, 4, 1),
-    Q3_ALT(Q3_CFG(PRO_QUANT, EPI_RESID, 12288, 512, 4, 1, 4, 1))
-    // (r04: the whole 12 KiB row of a wave requested before the prologue, two 6 KiB tiles: 13.3 vs 11.8 us; 9728 as 2 x 5 KiB: 9.2
-    // vs 8.3 us -- request depth at entry is not what these launches wait for)
-    Q3_CFG(PRO_QUANT, EPI_RESID, 2048, 512, 4, 1, 2, 0),
-    Q3_ALT(Q3_CFG(PRO_QUANT, EPI_RESID, 2048, 256, 4, 1, 2, 0))
-    Q3_CFG(PRO_QUANT, EPI_RESID, 4096, 1024, 4, 1, 4, 0),
-    Q3_ALT(Q3_CFG(PRO_QUANT, EPI_RESID, 4096, 512, 4, 1, 4, 0))
-    // --- final RMSNorm + classifier (streaming: two tiles requested before the prologue)
-    Q3_CFG(PRO_NORM, EPI_LOGITS, 1024, 512, 4, 8, 1, 1),
-    Q3_ALT(Q3_CFG(PRO_NORM, EPI_LOGITS, 1024, 256, 4, 8, 1, 1))
-    Q3_CFG(PRO_NORM, EPI_LOGITS, 2560, 512, 4, 2, 3, 1),
-    Q3_ALT(Q3_CFG(PRO_NORM, EPI_LOGITS, 2560, 256, 4, 2, 3, 1))
-    Q3_CFG(PRO_NORM, EPI_LOGITS, 4096, 512, 4, 2, 4, 1),
+// Notes on the entries of Q3_CFG_LIST (a macro: the list is expanded twice, reference-order fold and tolerance-mode tree fold):
+// --- QKV: RMSNorm_att + quantize + wq|wk|wv
+// (dim 1024, end of r03: the 512-thread / two-rows-per-wave forms lead the 1024-thread ones by 0.1 us per launch since the
+// wave-0 block loads go through LDS; same-process A/B of the three 0.6B changes below: 1,552-1,567 -> 1,582-1,599 tok/s)
+// (r04 sweep, 4B: 12 waves x 2 rows = 6,144 rows exactly, 6.18 vs 6.56 us; the same form at 4096 is slower, 8.33 vs 7.94 us)
+// (r04) 12-wave workgroups: 6,144 rows = 3,072 waves x 2 rows, every byte of the launch requested at kernel entry
+// --- W1|W3 + SwiGLU
+// (r05 re-sweep on the 4B shape, six alternations on one box: 8-wave workgroups 1,367 vs 1,387 us per token at 32 tokens, 2,148 vs
+// 2,164 at position 2,300 -- the 16-wave form had won in r04, before the attention and prologue changes of this round)
+// (r04: a 12-wave PF = 1 form still spills 92 B at 4096 and ran at 30.4 us; 2560: 16.5 vs 12.6 us -- not kept)
+// --- Wo behind the short-context attention kernel (xb arrives quantized): register-direct activation
+// --- quantize + W2 (and Wo of the long-context plan)
+// (r04: the whole 12 KiB row of a wave requested before the prologue, two 6 KiB tiles: 13.3 vs 11.8 us; 9728 as 2 x 5 KiB: 9.2
+// vs 8.3 us -- request depth at entry is not what these launches wait for)
+// --- final RMSNorm + classifier (streaming: two tiles requested before the prologue)
+#define Q3_CFG_LIST \
+    Q3_CFG_NORM_QKV(1024, 512, 2, 2, 1, 0), \
+    Q3_ALT(Q3_CFG_NORM_QKV(1024, 1024, 1, 1, 1, 0), Q3_CFG_NORM_QKV(1024, 1024, 4, 1, 1, 0), Q3_CFG_NORM_QKV(1024, 256, 4, 2, 1, 0)) \
+    Q3_CFG_NORM_QKV(2560, 768, 4, 2, 3, 0), \
+    Q3_ALT(Q3_CFG_NORM_QKV(2560, 1024, 4, 1, 3, 0), Q3_CFG_NORM_QKV(2560, 1024, 4, 1, 3, 1), Q3_CFG_NORM_QKV(2560, 1024, 4, 2, 3, 0)) \
+    Q3_CFG_NORM_QKV(4096, 1024, 4, 1, 4, 0), \
+    Q3_ALT(Q3_CFG_NORM_QKV(4096, 1024, 4, 1, 4, 1), Q3_CFG_NORM_QKV(4096, 1024, 4, 2, 4, 0), Q3_CFG_NORM_QKV(4096, 768, 4, 2, 4, 0)) \
+    Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 512, 2, 4, 1, 0), \
+    Q3_ALT(Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 1024, 1, 2, 1, 0), Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 1024, 4, 2, 1, 0), \
+           Q3_CFG(PRO_NORM, EPI_SWIGLU, 1024, 256, 4, 4, 1, 0)) \
+    Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 512, 4, 2, 3, 0), \
+    Q3_ALT(Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 512, 4, 2, 3, 1), Q3_CFG(PRO_NORM, EPI_SWIGLU, 2560, 1024, 4, 2, 3, 0)) \
+    Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 1024, 4, 2, 4, 0), \
+    Q3_ALT(Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 512, 4, 2, 4, 1), Q3_CFG(PRO_NORM, EPI_SWIGLU, 4096, 512, 4, 2, 4, 0)) \
+    Q3_CFG(PRO_PREQR, EPI_RESID, 2048, 256, 4, 1, 2, 0), \
+    Q3_ALT(Q3_CFG(PRO_PREQR, EPI_RESID, 2048, 512, 4, 1, 2, 0)) \
+    Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 256, 4, 1, 4, 0), \
+    Q3_ALT(Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 256, 4, 2, 4, 0), Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 512, 4, 1, 4, 0), \
+           Q3_CFG(PRO_PREQR, EPI_RESID, 4096, 1024, 4, 1, 4, 0)) \
+    Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 256, 4, 1, 3, 0), \
+    Q3_ALT(Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 512, 4, 1, 3, 0), Q3_CFG(PRO_QUANT, EPI_RESID, 3072, 1024, 4, 1, 3, 0)) \
+    Q3_CFG(PRO_QUANT, EPI_RESID, 9728, 1024, 4, 1, 2, 1), \
+    Q3_ALT(Q3_CFG(PRO_QUANT, EPI_RESID, 9728, 512, 4, 1, 2, 1)) \
+    Q3_CFG(PRO_QUANT, EPI_RESID, 12288, 1024, 4, 1, 4, 1), \
+    Q3_ALT(Q3_CFG(PRO_QUANT, EPI_RESID, 12288, 512, 4, 1, 4, 1)) \
+    Q3_CFG(PRO_QUANT, EPI_RESID, 2048, 512, 4, 1, 2, 0), \
+    Q3_ALT(Q3_CFG(PRO_QUANT, EPI_RESID, 2048, 256, 4, 1, 2, 0)) \
+    Q3_CFG(PRO_QUANT, EPI_RESID, 4096, 1024, 4, 1, 4, 0), \
+    Q3_ALT(Q3_CFG(PRO_QUANT, EPI_RESID, 4096, 512, 4, 1, 4, 0)) \
+    Q3_CFG(PRO_NORM, EPI_LOGITS, 1024, 512, 4, 8, 1, 1), \
+    Q3_ALT(Q3_CFG(PRO_NORM, EPI_LOGITS, 1024, 256, 4, 8, 1, 1)) \
+    Q3_CFG(PRO_NORM, EPI_LOGITS, 2560, 512, 4, 2, 3, 1), \
+    Q3_ALT(Q3_CFG(PRO_NORM, EPI_LOGITS, 2560, 256, 4, 2, 3, 1)) \
+    Q3_CFG(PRO_NORM, EPI_LOGITS, 4096, 512, 4, 2, 4, 1), \
     Q3_ALT(Q3_CFG(PRO_NORM, EPI_LOGITS, 4096, 256, 4, 2, 4, 1))
+#define Q3_CFG_FIN 1
+const GemvCfg kGemvCfgs[] = {
+Q3_CFG_LIST
 };
+#undef Q3_CFG_FIN
+// Q3_FLAG_FAST engines: the default form of every role with the wavefront-tree group fold (k_gemv FIN = 2); no alternates
+#undef Q3_ALT
+#define Q3_ALT(...)
+#define Q3_CFG_FIN 2
+const GemvCfg kGemvCfgsFast[] = {
+Q3_CFG_LIST
+};
+#undef Q3_CFG_FIN
 }  // namespace
 
 namespace q3inst {
-const GemvCfg* find_cfg(int pro, int epi, int n, int G, int which) {
+const GemvCfg* find_cfg(int pro, int epi, int n, int G, int which, bool fast) {
     if (G != 64 || which < 0) return nullptr;
+    if (fast) {                      // tolerance mode: the default form of the role with the tree fold (candidate 0 only)
+        if (which != 0) return nullptr;
+        for (const GemvCfg& c : kGemvCfgsFast)
+            if (c.pro == pro && c.epi == epi && c.n == n) return &c;
+        return nullptr;
+    }
     for (const GemvCfg& c : kGemvCfgs)
         if (c.pro == pro && c.epi == epi && c.n == n && which-- == 0) return &c;
     return nullptr;                  // no such candidate: the caller falls back to the generic kernel (a sweep sees "generic", not a mislabel)
