@@ -110,13 +110,24 @@ __global__ __launch_bounds__(kWG) void k_bquant(const GemvArgs a0, const BQuantA
 // 8-10 us for a few hundred KB) -- while the normalise / divide / round / pack work, which is instruction-issue bound
 // (~110 instructions per float4), is cut into slices of whole quantization groups.  Same arithmetic per element as
 // k_bquant, so the packed operands are identical.
-template <int PRO>
+#ifdef Q3_DEV
+#define BQ_STAMP(i) do { if (a.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BQ_STAMP(i) do { } while (0)
+#endif
+// N_T / PARTS_T > 0 (round 6): vector length and parts per stream at compile time, group 64 -- the listed models' shapes.  The generic
+// form computes term_index (two divisions by the block length per float4), the quantizer's group bookkeeping and the packed
+// operand address (four more) with run-time integer divisions, ~40 instructions each on this ISA: in-kernel stamps put 1,350
+// cycles on the pack loop alone and ~1,000 on the quantize step of ONE float4 (profiles/r06_bquant_stamps.txt).
+template <int PRO, int N_T = 0, int PARTS_T = 0>
 __global__ __launch_bounds__(kWG) void k_bquant_split(const GemvArgs a, const BQuantArgs b) {
     static_assert(PRO == PRO_NORM || PRO == PRO_QUANT, "embedding rows keep the single-workgroup kernel");
+    static_assert((N_T == 0) == (PARTS_T == 0) && (N_T == 0 || (N_T % (PARTS_T * 64)) == 0), "whole groups per part");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int sidx = blockIdx.y, part = blockIdx.x, nparts = gridDim.x;
+    const int sidx = blockIdx.y, part = blockIdx.x, nparts = PARTS_T ? PARTS_T : (int)gridDim.x;
     const int tid = threadIdx.x;
-    const int n = a.n, G = a.group, nv = n >> 2, glanes = G >> 2;
+    BQ_STAMP(0);
+    const int n = N_T ? N_T : a.n, G = N_T ? 64 : a.group, nv = n >> 2, glanes = G >> 2;
     const int nvp = nv / nparts;                       // float4 slots of this part (a whole number of groups: host)
     const int v0 = part * nvp;
     const v4f* x4 = (const v4f*)(a.in + (size_t)sidx * b.in_stride);
@@ -145,11 +156,14 @@ __global__ __launch_bounds__(kWG) void k_bquant_split(const GemvArgs a, const BQ
         }
         float ss;
         if (a.strict) {
+            BQ_STAMP(1);
             __syncthreads();
+            BQ_STAMP(2);
             if (tid < 64) {                                // (one wave: see gemv_prologue_finish)
                 ss = seq_sum_terms(sq, n);
                 if (tid == 0) red[0] = ss;
             }
+            BQ_STAMP(3);
             __syncthreads();
             ss = red[0];
         } else {
@@ -169,9 +183,12 @@ __global__ __launch_bounds__(kWG) void k_bquant_split(const GemvArgs a, const BQ
             if (k >= 2) { t = x4[v0 + vl]; if (PRO == PRO_NORM) w = ((const v4f*)a.norm_w)[v0 + vl]; }
             y = (PRO == PRO_NORM) ? norm4(w, f, t) : t;
         }
-        quantize4_to_lds(y, vl, glanes, valid, xq, xs);
+        if constexpr (N_T > 0) quantize4_to_lds<16>(y, vl, 16, valid, xq, xs);
+        else quantize4_to_lds(y, vl, glanes, valid, xq, xs);
     }
+    BQ_STAMP(4);
     __syncthreads();
+    BQ_STAMP(5);
     // packed MFMA operand order (see k_bquant): 16-byte pieces of this part
     const int ng = n / G, nj = G >> 6;
     const int nt = sidx >> 4, s = sidx & 15;
@@ -185,6 +202,10 @@ __global__ __launch_bounds__(kWG) void k_bquant_split(const GemvArgs a, const BQ
     }
     const int g0 = (v0 * 4) / G, ngp = (nvp * 4) / G;
     for (int gl = tid; gl < ngp; gl += kWG) b.xs_p[((size_t)nt * ng + g0 + gl) * 16 + s] = xs[gl];
+    BQ_STAMP(6);
+#ifdef Q3_DEV
+    if (a.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.stamps[15] = 0xB0ull + (unsigned)PRO;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
