@@ -79,12 +79,16 @@ struct BQuantArgs {
     int n_streams;
 };
 
-template <int PRO>
+// N_T > 0 (round 6): the listed models' vector lengths at group 64 as compile-time constants -- the generic prologue's slot counts,
+// term_index and group bookkeeping and the pack loop's operand address are run-time integer divisions otherwise (a dense prefill
+// block runs one of these workgroups per position: 2,048 per launch, instruction bound).
+template <int PRO, int N_T = 0>
 __global__ __launch_bounds__(kWG) void k_bquant(const GemvArgs a0, const BQuantArgs b) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr bool kStage = (PRO == PRO_NORM || PRO == PRO_EMBED_NORM);
     const int sidx = blockIdx.y;                 // blockIdx.x == 0: the prologue's "workgroup 0" side outputs are per stream
     GemvArgs a = a0;
+    if constexpr (N_T > 0) { a.n = N_T; a.group = 64; }
     a.in = a0.in ? a0.in + (size_t)sidx * b.in_stride : nullptr;
     a.st = a0.st + sidx;
     a.x_out = a0.x_out ? a0.x_out + (size_t)sidx * b.x_out_stride : nullptr;
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(kWG) void k_bquant(const GemvArgs a0, const BQuantA
     const GemvSmem sm = gemv_carve(smem_raw, a.n, a.group, 1, kStage);
     ProRegs<PRO> pr;
     gemv_prologue_issue<PRO>(a, pr);
-    gemv_prologue_finish<PRO, 0>(a, sm, pr);     // ends with __syncthreads(): sm.xq / sm.xs complete
+    gemv_prologue_finish<PRO, (N_T > 0 ? 4 : 0)>(a, sm, pr);     // ends with __syncthreads(): sm.xq / sm.xs complete
     const int n = a.n, G = a.group, ng = n / G, nj = G >> 6;
     const int nt = sidx >> 4, s = sidx & 15;
     for (int p = threadIdx.x; p < (n >> 4); p += kWG) {
