@@ -148,15 +148,25 @@ __global__ __launch_bounds__(kWG) void k_bquant_split(const GemvArgs a, const BQ
     }
     if (PRO == PRO_NORM) {
         float* sq = (float*)base;                      // term_floats(n) squares in the exact-sum layout
-        float* red = sq + term_floats(n);              // 64 floats
-        base += 4 * (size_t)(term_floats(n) + 64);
+        float* red = sq + term_floats(n);              // 64 floats + 64 approximate block totals
+        base += 4 * (size_t)(term_floats(n) + 128);
+        // specialised shapes whose exact-sum block is 4 / 8 / 16 consecutive float4 (= consecutive threads): the approximate block
+        // totals the sum wave starts from are formed here by all four waves (a 4-step DPP sum) instead of by the sum wave alone
+        // (64 dependent-ish adds, ~300 cycles in front of its first round)
+        constexpr int LPB = N_T > 0 ? spec_blen(N_T > 0 ? N_T : 1024) >> 2 : 0;
+        constexpr bool kApprox = N_T > 0 && spec_ok(N_T > 0 ? N_T : 1024) && (LPB == 4 || LPB == 8 || LPB == 16) && ((N_T >> 2) % kWG) == 0;
         float part_sum = 0.0f;
         for (int v = tid; v < nv; v += kWG) {
             const v4f t = x4[v];
             v4f q2;
             q2.x = t.x * t.x; q2.y = t.y * t.y; q2.z = t.z * t.z; q2.w = t.w * t.w;   // layers.rs:113
             *(v4f*)(sq + term_index(4 * v, n)) = q2;
-            part_sum = part_sum + sumsq4(t);
+            const float p4 = sumsq4(t);
+            part_sum = part_sum + p4;
+            if constexpr (kApprox) {
+                const float bt = group_sum_f32(p4, LPB);
+                if ((v & (LPB - 1)) == 0) red[64 + v / LPB] = bt;
+            }
         }
         float ss;
         if (a.strict) {
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(kWG) void k_bquant_split(const GemvArgs a, const BQ
             __syncthreads();
             BQ_STAMP(2);
             if (tid < 64) {                                // (one wave: see gemv_prologue_finish)
-                ss = seq_sum_terms(sq, n);
+                ss = seq_sum_terms(sq, n, kApprox ? red + 64 : nullptr);
                 if (tid == 0) red[0] = ss;
             }
             BQ_STAMP(3);
@@ -1508,8 +1518,11 @@ __device__ __forceinline__ void gqa_store(const AttnArgs& a0, size_t sbi, int h,
     if (a0.pack_q != nullptr) {
         // the Wo matmul's activation prologue, fused: quantize this head's hd outputs (hd % G == 0, so its groups
         // are whole) exactly as tensor.rs:91-119 and store them in the packed operand order of q3_batch.h
+        // (G is a power of two >= 64 on this path -- the packed operand order has G / 64 pieces per lane quarter -- so every
+        // quotient below is a shift: as run-time divisions they were ~40 instructions each, ten per lane, in every workgroup's tail)
         const int G = a0.group, upg = G >> 6, nj = G >> 6;
-        const int ngx = (a0.n_heads * hd) / G;
+        const int lg = __builtin_ctz((unsigned)G), lnj = lg - 6;
+        const int ngx = (a0.n_heads * hd) >> lg;
         const int nt = (int)(sbi >> 4), s = (int)(sbi & 15);
         float mu[4];
 #pragma unroll
@@ -1523,10 +1536,10 @@ __device__ __forceinline__ void gqa_store(const AttnArgs& a0, size_t sbi, int h,
                 const float scale = m / 127.0f;
                 const int qv = (scale != 0.0f) ? quant_round_i8(o[u] / scale) : 0;
                 const int k0 = h * hd + 64 * u + lane;
-                const int g = k0 / G, within = (k0 % G) >> 4;
-                const int qq = within / nj, j = within % nj;
+                const int g = k0 >> lg, within = (k0 & (G - 1)) >> 4;
+                const int qq = within >> lnj, j = within & (nj - 1);
                 a0.pack_q[((((size_t)nt * ngx + g) * nj + j) * 64 + (qq * 16 + s)) * 16 + (k0 & 15)] = (int8_t)qv;
-                if ((k0 % G) == 0) a0.pack_s[((size_t)nt * ngx + g) * 16 + s] = scale;
+                if ((k0 & (G - 1)) == 0) a0.pack_s[((size_t)nt * ngx + g) * 16 + s] = scale;
             }
         }
     }

@@ -21,6 +21,9 @@ for idx in range(0, 40):
     if lib.q3_dev_batch_stamps(t._h, idx, buf) != 0:
         break
     if (buf[15] & ~0xf) != 0xB0:
+        a = [buf[i] for i in range(5)]
+        if a[0] and a[4] > a[0] and a[4] - a[0] < 10**7 and all(a[i + 1] >= a[i] for i in range(4)):
+            print(f"launch {idx:2d} attention (k_attn_gqa2, stream 31 / kv head 3): norm+rope {a[1]-a[0]}  scores {a[2]-a[1]}  softmax {a[3]-a[2]}  V {a[4]-a[3]}  total {a[4]-a[0]}")
         continue
     st = [buf[i] for i in range(7)]
     print(f"launch {idx:2d} PRO {buf[15] & 0xf}: " + "  ".join(f"{st[i] - st[0]:6d}" if st[i] else "     -" for i in range(1, 7)))
