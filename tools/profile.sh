@@ -9,10 +9,14 @@ keep_stats() { f=$(find $out/$1 -name "*kernel_stats.csv" 2>/dev/null | head -1)
 keep_pmc() { f=$(find $out/$1 -name "*counter_collection.csv" 2>/dev/null | head -1); [ -n "$f" ] && python3 tools/pmc_collect.py $f $out/$1.json > /dev/null; rm -rf $out/$1; }
 trace() { name=$1; shift; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$name -o t -- "$@" > $out/$name.out 2> $out/$name.err; echo "$name trace rc=$?"; keep_stats $name; }
 pmc() { name=$1; ctrs=$2; shift; shift; timeout 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out/$name -o p -- "$@" > /dev/null 2> $out/$name.err; echo "$name pmc rc=$?"; keep_pmc $name; }
+ensure() { python3 -c "
+import sys; sys.path.insert(0,'qwen3-rs_amd')
+from qwen3_rs_amd import checkpoint as ck
+ck.ensure_synthetic_checkpoint('/tmp/q3_$1.bin', ck.SHAPES['$1'], seed=1234)"; }
 for sec in "$@"; do
   case $sec in
-    bench)    Q3_EAGER_LAUNCH=1 trace bench python3 bench.py --worker --steps 128 --warmup 8 --no-tolerance-mode ;;
-    bench8b)  Q3_EAGER_LAUNCH=1 trace bench_qwen3-8b python3 bench.py --worker --shape qwen3-8b --steps 32 --warmup 4 --no-tolerance-mode ;;
+    bench)    ensure qwen3-0.6b; Q3_EAGER_LAUNCH=1 trace bench python3 bench.py --worker --steps 128 --warmup 8 --no-tolerance-mode ;;
+    bench8b)  ensure qwen3-8b; Q3_EAGER_LAUNCH=1 trace bench_qwen3-8b python3 bench.py --worker --shape qwen3-8b --steps 32 --warmup 4 --no-tolerance-mode ;;
     batch)    Q3_EAGER_LAUNCH=1 trace batch python3 tools/bench_batch.py --steps 16 --verify 0 ;;
     prefill)  Q3_EAGER_LAUNCH=1 trace prefill python3 tools/prefill_prof.py ;;
     long4b)   Q3_EAGER_LAUNCH=1 Q3_PROFILE_FAMILIES=0 trace chat_decode_pos2300 python3 tools/longctx_prof.py qwen3-4b 2300 32 ;;

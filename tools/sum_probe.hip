@@ -87,6 +87,80 @@ __global__ __launch_bounds__(256) void k_sum(float* out, unsigned long long* cyc
     if (tid == 0) { cyc[0] = t1 - t0; rounds[0] = r; }
 }
 
+// Round 6: the exact sum on FOUR waves.  Wave w owns blocks 64 w .. 64 w + 63 of 16 terms (lane = block, terms in
+// registers).  Every wave runs the guess -> correct -> verify loop on its own quarter from a GUESSED input -- no barrier inside the
+// loop -- ; wave 0's input (-0.0) is exact, so its result is.  Wave w > 0 then takes wave w - 1's exact output from LDS (flag), and
+// if it differs from its guess translates its inputs by the difference and re-runs its loop.  Exact by the same argument as
+// spec_sum_lanes: every link inside a wave is verified bitwise, and every wave's input is the verified output of the one before.
+__device__ __forceinline__ float wave4_exact_sum16(const v4f (&r)[4], int nblk, float* lds, int* rounds_out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* lds_tot = lds;                 // [4] approximate wave totals
+    volatile float* lds_val = lds + 8;    // [4] exact output of wave w
+    volatile int* lds_flag = (volatile int*)(lds + 16);   // [4]
+    const int b = 64 * wave + lane;
+    const bool live = b < nblk;
+    const int nlive = min(max(nblk - 64 * wave, 0), 64);         // live lanes of this wave (wave-uniform)
+    float tot = 0.0f;
+    if (live) tot = ((r[0].x + r[0].y) + (r[0].z + r[0].w)) + ((r[1].x + r[1].y) + (r[1].z + r[1].w)) +
+                    (((r[2].x + r[2].y) + (r[2].z + r[2].w)) + ((r[3].x + r[3].y) + (r[3].z + r[3].w)));
+    const float inc = wave_scan_incl(tot);
+    if (lane == 63) lds_tot[wave] = inc;
+    if (tid < 4) lds_flag[tid] = 0;
+    __syncthreads();
+    float off = 0.0f;
+    for (int w = 0; w < wave; ++w) off += lds_tot[w];
+    float sc = wave_prev_lane(inc) + off;                        // approximate running sum in front of block b
+    if (b == 0) sc = -0.0f;
+    int nr = 0;
+    auto fold = [&](float s0) { s0 = chain4(s0, r[0]); s0 = chain4(s0, r[1]); s0 = chain4(s0, r[2]); s0 = chain4(s0, r[3]); return s0; };
+    float out = 0.0f;
+    auto converge = [&]() {                                      // lane 0's input is taken as given
+        for (int round = 0; round < 66; ++round) {
+            out = fold(sc);
+            ++nr;
+            const float prev = wave_prev_lane(out);
+            const bool ok = lane == 0 || !live || (__float_as_uint(prev) == __float_as_uint(sc));
+            if (__all(ok)) break;
+            float e = prev - sc;
+            if (lane == 0 || !live) e = 0.0f;
+            sc = sc + wave_scan_incl(e);
+        }
+    };
+    if (nlive > 0) converge();
+    float in0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), 0));
+    if (wave > 0) {
+        while (lds_flag[wave - 1] == 0) __builtin_amdgcn_s_sleep(1);
+        const float exact_in = lds_val[wave - 1];
+        if (nlive > 0 && __float_as_uint(exact_in) != __float_as_uint(in0)) {
+            const float delta = exact_in - in0;
+            sc = lane == 0 ? exact_in : sc + delta;
+            converge();
+        }
+        in0 = exact_in;
+    }
+    const float res = nlive > 0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(out), nlive > 0 ? nlive - 1 : 0)) : in0;
+    if (lane == 0) { lds_val[wave] = res; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); lds_flag[wave] = 1; }
+    if (rounds_out && wave == 3 && lane == 0) *rounds_out = nr;
+    while (lds_flag[3] == 0) __builtin_amdgcn_s_sleep(1);
+    return lds_val[3];
+}
+__global__ __launch_bounds__(256) void k_sum4(float* out, unsigned long long* cyc, int* rounds, const float* x, int n, int variant) {
+    __shared__ float lds[32];
+    const int tid = threadIdx.x;
+    const int nblk = n / 16;
+    v4f r[4];
+    const v4f* bp = (const v4f*)x + 4 * min(tid, nblk - 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v4f q = bp[k]; q.x = q.x * q.x; q.y = q.y * q.y; q.z = q.z * q.z; q.w = q.w * q.w; r[k] = q; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned long long t0 = now();
+    const float s = wave4_exact_sum16(r, nblk, lds, rounds);
+    const unsigned long long t1 = now();
+    out[tid] = s;
+    if (tid == 0) cyc[0] = t1 - t0;
+}
+
 int main() {
     float *din, *dout; unsigned long long* dcyc; int* drounds;
     const int n = 1024;
@@ -123,6 +197,8 @@ int main() {
             run("engine seq_sum_terms", k_sum<4>, 0);
             if (nn == 1024) { run("plain iteration, 64 x 16 terms", k_sum<4>, 1); run("plain iteration, 32 x 32 terms", k_sum<8>, 1); run("plain iteration, 16 x 64 terms", k_sum<16>, 1); }
             if (nn == 4096) { run("plain iteration, 64 x 64 terms", k_sum<16>, 1); }
+            if (nn != 1024) run("4 waves x 64 lanes x 16 terms", k_sum4, 0);
+            else run("4 waves, 64 blocks of 16 (1 wave live)", k_sum4, 0);
         }
     }
     return 0;
