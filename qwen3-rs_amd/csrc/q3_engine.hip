@@ -179,6 +179,9 @@ int env_int(const char* name, int dflt) {
 // in Q3_FLAG_FAST mode (no exact sum in front of the quantizer) it is worth +6 % on the 0.6B shape.
 // r05 re-sweep: only the 16-wave forms still carried the barrier (8B QKV / W1|W3): 1,895.7 with it vs 1,885.9 us per token without
 // (three alternations) -- off everywhere in reference-order mode now; the developer switch keeps the form for the FAST-mode A/B.
+// r06, the same question in Q3_FLAG_FAST mode (64-token device loop, two alternations, tok/s without / with the barrier): 0.6B
+// 1,827 / 1,820 vs 1,815 / 1,817; 4B 741 / 742 vs 739 / 739; 8B 535 / 535 vs 537 / 540 -- the r03 "+6 %" is gone (the block loads
+// of x are coalesced since then): off in both modes.
 int xfirst_dflt(int wgt) { return wgt >= 1024 ? dev_knob("Q3_XFIRST_DEFAULT", 0) : 0; }
 
 

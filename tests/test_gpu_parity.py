@@ -332,6 +332,26 @@ def test_forward_vs_oracle_live(q3, oracle, tmp_ckpt_dir, name, ctx):
             assert np.max(np.abs(a - b)) <= 2e-5, np.max(np.abs(a - b))
 
 
+@pytest.mark.parametrize("name", ["qwen3-0.6b-dims-l2", "qwen3-4b-dims-l2", "qwen3-8b-dims-l2"])
+def test_tolerance_mode_on_the_listed_layer_dims(q3, oracle, name):
+    """Q3_FLAG_FAST on the shapes whose GEMV launches take the tree-fold instantiations (k_gemv FIN = 2, round 6) next to the tree
+    RMSNorm / attention sums.  Stated tolerance: max |delta logit| <= 0.15 x the standard deviation of the oracle's logits on a
+    2-layer stack.  The deviation is bimodal -- ~1e-6 x the logit scale while no re-quantized activation changes its int8 value, and
+    1e-3 .. 6e-2 x once one does (the flip is amplified by the following W8A8 layers; measured max 0.061 x on the 8B dims) -- which
+    is why this mode is opt-in and never the benchmark's `value`."""
+    ck = q3.checkpoint
+    path = os.path.join(os.environ.get("Q3_CKPT_DIR", "/tmp"), f"q3_{name}.bin")
+    ck.ensure_synthetic_checkpoint(path, ck.SHAPES[name], seed=1235)
+    om = oracle.OracleModel(path, 256)
+    with q3.TransformerBuilder(path).with_ctx_length(256).with_strict(False).build() as t:
+        tok = 3
+        for pos in range(6):
+            a, b = np.array(t.forward(tok, pos), copy=True), om.forward(tok, pos)
+            assert np.all(np.isfinite(a))
+            assert np.max(np.abs(a - b)) <= 0.15 * np.std(b), (name, pos, np.max(np.abs(a - b)), np.std(b))
+            tok = oracle.sample_argmax(b)
+
+
 @pytest.mark.parametrize("name", ["qwen3-4b-dims-l2", "qwen3-8b-dims-l2"])
 def test_big_layer_dims_vs_oracle(q3, oracle, name):
     """BASELINE configs 3-5 use the 4B / 8B layer shapes: row lengths 2560 / 9728 (not multiples of 1 KiB),
