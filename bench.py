@@ -371,7 +371,7 @@ def tolerance_mode_block(q3, eng, path, args, device, first_tok, first_pos, n_lo
             "what": "tree reductions (RMSNorm sum of squares, QK-norm, attention scores / softmax sum / value sums, GEMV group fold) "
                     "instead of the reference's sequential f32 sums; int8 group dots exact in both modes.  Never `value`: on the "
                     "synthetic checkpoint's near-flat logits a 1e-7 reordering difference is amplified by the re-quantisation "
-                    "steps and flips greedy tokens (DESIGN.md, Numerics)"}
+                    "steps and flips greedy tokens (DESIGN.md section 3)"}
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -77,7 +77,7 @@ typedef struct q3_engine q3_engine;
  * BIT-IDENTICAL to the CPU path and greedy token sequences are identical by construction. */
 #define Q3_FLAG_FAST 1u /* opt-in: wavefront-tree reductions for the RMSNorm / attention sums.  Not
                            bit-exact: a 28-layer W8A8 stack amplifies a 1e-7 reordering difference to its
-                           own int8 quantization-noise floor (logit deltas of ~0.1, see DESIGN.md), so
+                           own int8 quantization-noise floor (logit deltas of ~0.1, see DESIGN.md section 3), so
                            greedy tokens can differ from the CPU path.  The int8 group-quant matmul itself
                            is bit-exact in both modes. */
 #define Q3_FLAG_NO_GRAPH 2u /* launch kernels eagerly instead of replaying a captured hipGraph */

@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # Q3_ORACLE_LIB selects another build of the same source (the ASan/UBSan one: `make -C oracle libq3_oracle_asan.so`,
-# run with LD_PRELOAD=$(gcc -print-file-name=libasan.so) -- see tests/README note in DESIGN.md section 7)
+# run with LD_PRELOAD=$(gcc -print-file-name=libasan.so) -- see docs/HISTORY.md section 6)
 _LIB_PATH = os.environ.get("Q3_ORACLE_LIB") or os.path.join(_HERE, "libq3_oracle.so")
 
 

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kS2Threads) void k_attn_short2(const AttnArgs a) {
         unsigned long long etv = 0ull;
         if (wave == 7 && lane < 32) etv = kExp2Tab[lane];
         // > 0: 8-row steps to request without waiting for the position (pos < 64) -- the position-range graphs lost their A/B
-        //  and exist in the developer build only; the product does not fetch the field
+        // (docs/HISTORY.md section 0) and exist in the developer build only; the product does not fetch the field
 #ifdef Q3_DEV
         const int hint = a.row_steps;
 #else

@@ -1002,7 +1002,7 @@ int q3_engine::capture() {
             HIP_TRY(hipMemcpyAsync(d_state, h_state, sizeof(State), hipMemcpyHostToDevice, stream));
             // (developer build, forward-only experiment: d_logits is NOT filled, so device-side sampling after q3_forward is undefined)
             // Q3_FWD_LOGITS_HOST=1: the classifier stores its logits straight into the pinned host buffer (device-visible,
-            // fine-grained) and the download node disappears (SURVEY section 7 "Logits egress"; measured in DESIGN section 7)
+            // fine-grained) and the download node disappears (SURVEY section 7 "Logits egress"; measured in docs/HISTORY.md section 7)
             const bool host_out = dev_knob("Q3_FWD_LOGITS_HOST", 0) != 0;
             for (const Launch& L : (lng ? plan_long : plan)) {
                 if (host_out && L.fam == F_LMHEAD && !L.is_attn && !L.is_next) {

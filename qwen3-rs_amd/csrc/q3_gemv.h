@@ -285,7 +285,7 @@ struct GemvArgs {
     int xfirst;
     // EPI_QKV: transposed copy of this layer's value cache, [kv_dim][seq_len] (nullptr: none).  The long-context output kernel walks
     // 16-element slices of the value rows over thousands of timesteps: in the row-major cache that is a 64-byte piece every 4 KB,
-    // here a contiguous run per element.  The value row of the current position is written to both.
+    // here a contiguous run per element (docs/HISTORY.md section 0, round 5).  The value row of the current position is written to both.
     float* v_t;
 };
 

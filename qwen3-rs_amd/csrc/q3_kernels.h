@@ -1488,7 +1488,7 @@ __global__ __launch_bounds__(kAoThreads) void k_attn_out(const AttnArgs a) {
                 // the next tile read behind the last burst, "tile consumed" stored behind it: bit-identical in most runs, 906 -> 902 us
                 // of attention per token at position 2,300, but 4 runs in 10 of the 33-chunk operator test returned a wrong 8-element
                 // slice, with or without a compiler barrier around the store.  The barrier stays; what the chain really waits for is
-                // the staging waves' value rows)
+                // the staging waves' value rows, see docs/HISTORY.md section 0.)
                 chain_request8(bv, (unsigned)(size_t)(vr + q + 8));           // (its wait also covers av, requested by the loop above)
                 chain_add16(o_s, av[0], av[1], av[2], av[3]);
                 chain_add16(o_s, av[4], av[5], av[6], av[7]);
