@@ -280,6 +280,38 @@ def test_host_sample_argmax_last_maximum_under_total_order(q3):
         assert lib.q3_host_sample_argmax(a.ctypes.data_as(fp), a.size, None) == want
 
 
+def test_bench_roofline_from_graph_stamps_arithmetic(monkeypatch):
+    """bench.py's roofline block from graph-replay kernel durations (tools/kstamps.py): achieved = algorithmic bytes of a token's k_gemv
+    launches / the sum of their stamped durations; the eager HIP-event figure is kept as eager_check; a stamped run of another build is
+    refused.  (The stamp run itself needs a GPU; its arithmetic does not.)"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench
+    import kstamps
+    from qwen3_rs_amd import checkpoint as ck
+    shape = ck.SHAPES["qwen3-0.6b"]
+    fam = {"qkv": (28, 3.0, 2.0), "attn": (28, 3.1, 1.4), "wo": (28, 1.7, 1.3), "w13": (28, 3.5, 1.3), "w2": (28, 2.4, 1.3), "lm_head": (1, 30.0, 1.4)}
+    gk = {"build_id": "abc", "stamped_build_id": "abc", "product_library_us_per_token": 540.0,
+          "stamped_developer_library_us_per_token": 620.0, "sum_duration_plus_gap_us_per_token": 626.0, "wall_us_per_token_this_call": 618.0,
+          "stamp_overhead_us_per_launch": 0.57, "tokens_folded": 68, "launches_per_token": 141,
+          "families": {k: {"launches_per_token": n, "avg_duration_us": d, "avg_gap_to_predecessor_us": g} for k, (n, d, g) in fam.items()}}
+    monkeypatch.setattr(kstamps, "graph_kernel_durations", lambda **kw: dict(gk))
+    args = bench.parse_args(["--steps", "20", "--warmup", "5"])
+    out = {"build_id": {"library": "abc", "sources": "abc"},
+           "roofline": {"bound": "hbm", "achieved": 1400.0, "frac": 0.175, "avg_launch_us": 4.2, "per_kernel": [], "note": "eager", "peak": 8000.0, "unit": "GB/s", "traffic": 5800000}}
+    bench.roofline_from_graph_stamps(out, args, shape, 5, 7, "/nonexistent")
+    rf = out["roofline"]
+    bpl = bench.gemv_bytes_per_launch(shape)
+    want = sum(bpl[k] * n for k, (n, d, g) in fam.items() if k in bpl) / (sum(d * n for k, (n, d, g) in fam.items() if k in bpl) * 1e-6)
+    assert abs(rf["achieved"] - want / 1e9) < 0.1 and abs(rf["frac"] - want / 8e12) < 1e-4
+    assert rf["eager_check"]["frac"] == 0.175 and rf["launches_per_token"] == 113 and rf["traffic"] == 5800000
+    assert rf["graph_mode"]["stamp_overhead_us_per_launch"] == 0.57 and len(rf["per_kernel"]) == 6
+    assert sum(bpl[k] * n for k, (n, d, g) in fam.items() if k in bpl) == sum(shape.weight_bytes_per_token())   # SURVEY 8d: 633,233,408 B
+    out2 = {"build_id": {"library": "other"}, "roofline": dict(rf)}
+    with pytest.raises(RuntimeError):
+        bench.roofline_from_graph_stamps(out2, args, shape, 5, 7, "/nonexistent")
+
+
 def _two_replica_bench_check(extra):
     """Body shared by the CPU (stub engine) and the two-GPU (real engines) variants: `bench.py --gpus 2` is ONE line with
     n_gpus 2 whose whole-job value is (well above) one replica's."""
