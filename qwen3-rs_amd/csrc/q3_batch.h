@@ -1197,7 +1197,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_dgemm(const BGemmArgs a) {
     // memory round trip and drained the ring to 8 groups whatever DEPTH was -- r04 ablation: 12 us of a 28 us W1|W3 launch),
     // committed to the wave's single LDS slice in the last stage, after the last scale read of the current chunk
     constexpr int CH = DEPTH;
-    static_assert(DEPTH * 4 <= 64, "a scale chunk is one float4 per lane at most");
+    static_assert(DEPTH * 4 <= 128, "a scale chunk is two float4 per lane at most");
+    constexpr int SCN = (CH * 4 + 63) / 64;                      // float4 of a tile's scale chunk per lane (1; 2 for the 32-group ring)
     constexpr int CF = CH * 16;                                  // floats per scale chunk (CH groups x 16 rows / streams)
     static_assert(DEPTH % CH == 0, "whole chunks per ring iteration");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1248,7 +1249,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_dgemm(const BGemmArgs a) {
     for (int p = 0; p < PT; ++p) best[p] = 0ull;
     if (rtask < nrt) {
         const int ntk = (nrt - rtask + rstride - 1) / rstride;   // row tasks of this wave
-        const int sl = min(lane, CH * 4 - 1);                   // scale chunk: float4 index of this lane (upper lanes idle)
+        int sl[SCN];                                             // scale chunk: float4 indices of this lane (upper lanes idle)
+#pragma unroll
+        for (int i = 0; i < SCN; ++i) sl[i] = min(lane + 64 * i, CH * 4 - 1);
         const int nsv = ng * 4;                                  // float4 per scale tile
         // fragments by buffer loads: resource = the packed matrix (SGPRs), scalar offset = tile * ng KiB + group * 1 KiB, vector
         // offset = lane * 16 -- no vector ALU in the address path (flat global loads cost a 64-bit v_lshl_add per request)
@@ -1257,19 +1260,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_dgemm(const BGemmArgs a) {
         const int tile_b = ng << 10;                             // bytes per packed tile
         int cur = rtask, nxt = ntk > 1 ? rtask + rstride : rtask;        // current / next row task (a wave without a next one re-reads)
         int k = 0;
-        v4f sc[RT + PT];                                         // scale chunk in flight (global -> registers -> LDS)
+        v4f sc[RT + PT][SCN];                                    // scale chunk in flight (global -> registers -> LDS)
         auto chunk_load = [&](int task, int c) {                 // chunk c = groups [c*CH, +CH) of row task `task`
-            const int f0 = c * (CH * 4) + sl;
             const v4f* gws = (const v4f*)(a.ws + (size_t)(task * RT) * ng * 16);
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) sc[rt] = (gws + (size_t)rt * nsv)[f0];
+            for (int i = 0; i < SCN; ++i) {
+                const int f0 = c * (CH * 4) + sl[i];
 #pragma unroll
-            for (int p = 0; p < PT; ++p) sc[RT + p] = (gxs + (size_t)p * nsv)[f0];
+                for (int rt = 0; rt < RT; ++rt) sc[rt][i] = (gws + (size_t)rt * nsv)[f0];
+#pragma unroll
+                for (int p = 0; p < PT; ++p) sc[RT + p][i] = (gxs + (size_t)p * nsv)[f0];
+            }
         };
         auto chunk_commit = [&]() {
-            if (lane < CH * 4) {
 #pragma unroll
-                for (int kk = 0; kk < RT + PT; ++kk) ((v4f*)(lsc + (size_t)kk * CF))[lane] = sc[kk];
+            for (int i = 0; i < SCN; ++i) {
+                if (lane + 64 * i < CH * 4) {
+#pragma unroll
+                    for (int kk = 0; kk < RT + PT; ++kk) ((v4f*)(lsc + (size_t)kk * CF))[lane + 64 * i] = sc[kk][i];
+                }
             }
         };
         v4i fa[DEPTH][RT], fb[BMODE != 0 ? 1 : DEPTH];
