@@ -161,6 +161,71 @@ __global__ __launch_bounds__(256) void k_sum4(float* out, unsigned long long* cy
     if (tid == 0) cyc[0] = t1 - t0;
 }
 
+// The FLAT four-wave form: one guess -> correct -> verify loop over all 256 blocks, every round exchanging across the waves through
+// LDS (the last lane's output for the link check, then the waves' error totals and verdicts for the corrected inputs): two
+// workgroup barriers per round.
+__device__ __forceinline__ float wave4_flat_exact_sum16(const v4f (&r)[4], int nblk, float* lds, int* rounds_out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* lds_tot = lds;            // [4]
+    float* lds_out = lds + 4;        // [4] output of each wave's last lane
+    float* lds_e = lds + 8;          // [4] each wave's error total
+    int* lds_ok = (int*)(lds + 12);  // [4]
+    const int b = tid;
+    const bool live = b < nblk;
+    float tot = 0.0f;
+    if (live) tot = ((r[0].x + r[0].y) + (r[0].z + r[0].w)) + ((r[1].x + r[1].y) + (r[1].z + r[1].w)) +
+                    (((r[2].x + r[2].y) + (r[2].z + r[2].w)) + ((r[3].x + r[3].y) + (r[3].z + r[3].w)));
+    const float inc = wave_scan_incl(tot);
+    if (lane == 63) lds_tot[wave] = inc;
+    __syncthreads();
+    float off = 0.0f;
+    for (int w = 0; w < wave; ++w) off += lds_tot[w];
+    float sc = wave_prev_lane(inc) + off;
+    if (b == 0) sc = -0.0f;
+    float out = 0.0f;
+    int nr = 0;
+    for (int round = 0; round < 260; ++round) {
+        out = chain4(chain4(chain4(chain4(sc, r[0]), r[1]), r[2]), r[3]);
+        ++nr;
+        if (lane == 63) lds_out[wave] = out;
+        __syncthreads();
+        float prev = wave_prev_lane(out);
+        if (lane == 0 && wave > 0) prev = lds_out[wave - 1];
+        const bool ok = b == 0 || !live || (__float_as_uint(prev) == __float_as_uint(sc));
+        float e = prev - sc;
+        if (b == 0 || !live) e = 0.0f;
+        const float es = wave_scan_incl(e);
+        const int wok = __all(ok) ? 1 : 0;
+        if (lane == 63) { lds_e[wave] = es; lds_ok[wave] = wok; }
+        __syncthreads();
+        if (lds_ok[0] & lds_ok[1] & lds_ok[2] & lds_ok[3]) break;
+        float eoff = 0.0f;
+        for (int w = 0; w < wave; ++w) eoff += lds_e[w];
+        sc = sc + (es + eoff);
+        if (b == 0) sc = -0.0f;
+    }
+    if (tid == nblk - 1) lds_tot[0] = out;
+    if (rounds_out && tid == 0) *rounds_out = nr;
+    __syncthreads();
+    return lds_tot[0];
+}
+__global__ __launch_bounds__(256) void k_sum4f(float* out, unsigned long long* cyc, int* rounds, const float* x, int n, int variant) {
+    __shared__ float lds[32];
+    const int tid = threadIdx.x;
+    const int nblk = n / 16;
+    v4f r[4];
+    const v4f* bp = (const v4f*)x + 4 * min(tid, nblk - 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v4f q = bp[k]; q.x = q.x * q.x; q.y = q.y * q.y; q.z = q.z * q.z; q.w = q.w * q.w; r[k] = q; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned long long t0 = now();
+    const float s = wave4_flat_exact_sum16(r, nblk, lds, rounds);
+    const unsigned long long t1 = now();
+    out[tid] = s;
+    if (tid == 0) cyc[0] = t1 - t0;
+}
+
 int main() {
     float *din, *dout; unsigned long long* dcyc; int* drounds;
     const int n = 1024;
@@ -197,6 +262,7 @@ int main() {
             run("engine seq_sum_terms", k_sum<4>, 0);
             if (nn == 1024) { run("plain iteration, 64 x 16 terms", k_sum<4>, 1); run("plain iteration, 32 x 32 terms", k_sum<8>, 1); run("plain iteration, 16 x 64 terms", k_sum<16>, 1); }
             if (nn == 4096) { run("plain iteration, 64 x 64 terms", k_sum<16>, 1); }
+            if (nn != 1024) run("4 waves flat, 2 barriers per round", k_sum4f, 0);
             if (nn != 1024) run("4 waves x 64 lanes x 16 terms", k_sum4, 0);
             else run("4 waves, 64 blocks of 16 (1 wave live)", k_sum4, 0);
         }
